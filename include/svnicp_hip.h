@@ -1,0 +1,150 @@
+/*
+ * svnicp_hip.h — C ABI of libsvnicp_hip.so: MI355X (gfx950) Stein-variational ICP registration.
+ *
+ * This is the drop-in boundary for the reference's solver classes svnicp::SVGDICP (virtual) /
+ * svnicp::SVNICP (final).  The reference has no FFI: its only caller hands libtorch tensors on
+ * kCUDA and one gtsam::Pose3 to those classes (svn-icp/src/core/OdometryPipeline.cpp:282-288,
+ * 573-607, 1021).  Every entry point below names the reference interface it replaces
+ * (file:line relative to /root/reference/svn-icp/).  Plain pointers and sizes only; no torch,
+ * no C++ types.  All floating point is float64 (reference: include/core/SVGDICP.h:207), row-major.
+ *
+ * Threading: like the reference (one steinicp_thread_, OdometryPipeline.cpp:106-110) a context
+ * is used by one host thread at a time; calls are sequential per scan.  Ownership: the context
+ * owns all device memory; the caller owns every host buffer it passes in or out.
+ *
+ * Return convention: 0 (or a SteinICPState for svnicp_align) on success, a negative
+ * svnicp_status on failure; nothing throws across this ABI.  svnicp_last_error() gives text.
+ */
+#ifndef SVNICP_HIP_H
+#define SVNICP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVNICP_ABI_VERSION 1
+
+typedef struct svnicp_ctx svnicp_ctx;
+
+/* enum SteinICPState — include/core/SVGDICP.h:59-62 */
+#define SVNICP_ALIGN_SUCCESS 1
+#define SVNICP_NO_OPTIMIZER 2
+
+typedef enum {
+  SVNICP_OK = 0,
+  SVNICP_ERR_INVALID = -1,   /* bad argument / call order            */
+  SVNICP_ERR_HIP = -2,       /* a HIP runtime call failed             */
+  SVNICP_ERR_NO_DEVICE = -3, /* no gfx950 device / code object        */
+  SVNICP_ERR_NOMEM = -4
+} svnicp_status;
+
+/* class_type — OdometryPipeline.cpp:282-288 ("SVNICP" | "SVGDICP") */
+#define SVNICP_MODE_SVN 0
+#define SVNICP_MODE_SVGD 1
+
+/* optimizer names of SVGDICP::set_optimizer — src/core/SVGDICP.cpp:142-170 */
+#define SVNICP_OPT_ADAM 0
+#define SVNICP_OPT_RMSPROP 1
+#define SVNICP_OPT_SGD 2
+#define SVNICP_OPT_ADAGRAD 3
+#define SVNICP_OPT_NONE (-1)
+
+#define SVNICP_MEM_HOST 0
+#define SVNICP_MEM_DEVICE 1
+
+/* svnicp::SteinICPParam — include/core/SVGDICP.h:41-57 (solver-relevant fields; batch_size,
+ * normalize_cloud, convergence_steps, cov_filter_type are ignored by the reference solver) */
+typedef struct svnicp_params {
+  int32_t struct_size;           /* = sizeof(svnicp_params)                                   */
+  int32_t mode;                  /* SVNICP_MODE_*                                              */
+  int32_t iterations;            /* SteinICPParam::iterations                                  */
+  int32_t knn_count;             /* SteinICPParam::KNN_count  (K_source_)                      */
+  double lr;                     /* SteinICPParam::lr                                          */
+  double max_dist;               /* SteinICPParam::max_dist                                    */
+  double convergence_threshold;  /* SteinICPParam::convergence_threshold                       */
+  int32_t check_early_stop;      /* SteinICPParam::check_early_stop                            */
+  int32_t svn_full_grad;         /* SteinICPParam::SVN_full_grad                               */
+  int32_t optimizer;             /* SteinICPParam::optimizer as SVNICP_OPT_*                   */
+  int32_t record_trace;          /* test hook: keep per-iteration H,b,N,phi,h,correspondences  */
+} svnicp_params;
+
+/* ctor svnicp::SVNICP(param, init_pose[6,P,1], opt) / svnicp::SVGDICP(param, init_pose)
+ * — src/core/SVNICP.cpp:20-38, src/core/SVGDICP.cpp:22-44.  init_pose6xP may be NULL (then
+ * svnicp_set_particles must be called before svnicp_align).  `device` is the HIP ordinal. */
+int svnicp_create(const svnicp_params *params, int device, const double *init_pose6xP, int P,
+                  svnicp_ctx **out);
+void svnicp_destroy(svnicp_ctx *ctx);
+const char *svnicp_last_error(const svnicp_ctx *ctx); /* ctx may be NULL: last create() error */
+int svnicp_abi_version(void);
+
+/* run on this hipStream_t instead of the context's own stream (0 = back to own stream);
+ * lets a host that owns streams (torch, ROS executor) keep everything in one queue */
+int svnicp_set_stream(svnicp_ctx *ctx, void *hip_stream);
+int svnicp_synchronize(svnicp_ctx *ctx);
+
+/* SVGDICP::add_cloud(source[B,3], target[M,3], init_pose[6,P,1]) — src/core/SVGDICP.cpp:46-62.
+ * Split in two because the clouds and the particles are independent buffers; both are copied. */
+int svnicp_set_clouds(svnicp_ctx *ctx, const double *src_xyz, int64_t B, const double *tgt_xyz,
+                      int64_t M, int mem_kind);
+int svnicp_set_particles(svnicp_ctx *ctx, const double *init_pose6xP, int P);
+
+/* SVGDICP::set_initial_mean(gtsam::Pose3) — include/core/SVGDICP.h:102-110.
+ * R0 is the rotation matrix row-major (the reference's R0_ after its transpose), t0 the translation. */
+int svnicp_set_initial_mean(svnicp_ctx *ctx, const double R0_rowmajor[9], const double t0[3]);
+/* SVGDICP::set_k / set_threshold — include/core/SVGDICP.h:98,100 */
+int svnicp_set_k(svnicp_ctx *ctx, int k);
+int svnicp_set_max_dist(svnicp_ctx *ctx, double max_dist);
+
+/* SVNICP::stein_align() / SVGDICP::stein_align() — src/core/SVNICP.cpp:41-114,
+ * src/core/SVGDICP.cpp:66-140.  Synchronous.  Returns SVNICP_ALIGN_SUCCESS / SVNICP_NO_OPTIMIZER
+ * or a negative svnicp_status. */
+int svnicp_align(svnicp_ctx *ctx);
+/* same work, enqueued only (no host sync): for benchmarking / pipelining; results are valid after
+ * svnicp_synchronize() */
+int svnicp_align_async(svnicp_ctx *ctx);
+
+/* results — caller-allocated outputs, copied device -> host */
+int svnicp_get_transformation(svnicp_ctx *ctx, double out6[6]);      /* SVNICP.cpp:286-290 / SVGDICP.cpp:497-499 */
+int svnicp_get_distribution(svnicp_ctx *ctx, double out6[6]);        /* SVNICP.cpp:292-297 / SVGDICP.cpp:501-503 */
+int svnicp_get_cov_matrix(svnicp_ctx *ctx, double out36[36]);        /* SVNICP.cpp:299-308 / SVGDICP.cpp:505-513 */
+int svnicp_get_particles(svnicp_ctx *ctx, double *out6P);            /* SVGDICP.cpp:515-520: x..,y..,z..,rx..,ry..,rz.. */
+int svnicp_get_particle_weight(svnicp_ctx *ctx, double *outP);       /* SVNICP.cpp:281-284 / SVGDICP.cpp:522-524 */
+int svnicp_get_particle_history(svnicp_ctx *ctx, float *outIx6P);    /* SVGDICP.cpp:526-534: I rows of 6P float32 */
+int svnicp_get_runtime(svnicp_ctx *ctx, double out3[3]);             /* SVGDICP.h:94-96 {knn_s, update_s, finish_iter} */
+
+/* ---- split-phase entry points: one process per GPU, particles sharded across ranks ----------
+ * (new functionality; the reference is single-GPU).  Sequence per registration:
+ *   svnicp_set_shard -> svnicp_stage_candidates(b_lo,b_hi) -> [host all-gathers rows of
+ *   svnicp_candidates_devptr] -> svnicp_build_candidate_table -> per iteration:
+ *   svnicp_iter_accumulate -> [host all-gathers svnicp_sums_devptr, 22 doubles per particle] ->
+ *   svnicp_iter_update ; finally svnicp_finish.  svnicp_align == all of it with one shard. */
+int svnicp_set_shard(svnicp_ctx *ctx, int p_lo, int p_hi);
+int svnicp_align_begin(svnicp_ctx *ctx);
+int svnicp_stage_candidates(svnicp_ctx *ctx, int64_t b_lo, int64_t b_hi);
+int svnicp_build_candidate_table(svnicp_ctx *ctx);
+int svnicp_iter_accumulate(svnicp_ctx *ctx, int iteration);
+int svnicp_iter_update(svnicp_ctx *ctx, int iteration);
+int svnicp_finish(svnicp_ctx *ctx);
+int svnicp_stopped(svnicp_ctx *ctx);     /* 1 once the early-stop flag is set (syncs the stream) */
+void *svnicp_candidates_devptr(svnicp_ctx *ctx); /* int32 [B][K] */
+void *svnicp_sums_devptr(svnicp_ctx *ctx);       /* double [P][SVNICP_NSUMS] */
+#define SVNICP_NSUMS 22
+
+/* ---- test-only taps (parity tests; not part of the reference interface) -------------------- */
+int svnicp_get_candidates(svnicp_ctx *ctx, int32_t *outBK);          /* sourceKNN_idx_  SVGDICP.cpp:214 */
+int svnicp_get_candidate_dist2(svnicp_ctx *ctx, double *outBK);
+/* valid when params.record_trace != 0; any pointer may be NULL.
+ * corr: [I][P][B] int32 (-1 where not run), H [I][P][36], b [I][P][6], newton [I][P][6],
+ * phi [I][P][6], h [I] */
+int svnicp_get_trace(svnicp_ctx *ctx, int32_t *corr, double *H, double *b, double *newton,
+                     double *phi, double *h);
+/* elapsed GPU milliseconds of the last align, by phase: {stage A (candidates + table),
+ * iterations (accumulate + update), total} — measured with hipEvents on the context's stream */
+int svnicp_get_gpu_ms(svnicp_ctx *ctx, double out3[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVNICP_HIP_H */

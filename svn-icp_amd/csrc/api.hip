@@ -1,0 +1,474 @@
+// api.hip — the C ABI of libsvnicp_hip.so (include/svnicp_hip.h): context, device buffers,
+// launch sequencing.  Host-side mirror of the reference's solver object state
+// (include/core/SVGDICP.h:170-210): clouds, R0/t0, particles R_/t_, pose_particles_, history.
+// No CPU fallback: every compute entry point needs a gfx950 device and fails loudly without one.
+#include "../../include/svnicp_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace svnicp;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t ensure(size_t n) {
+    if (n <= cap && p) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct svnicp_ctx {
+  svnicp_params prm{};
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  std::string err;
+
+  int64_t B = 0, M = 0, Mp = 0;
+  int K = 0, S = 0, P = 0;
+  int p_lo = 0, p_hi = 0;
+  bool clouds_set = false, particles_set = false, particles_dirty = false, shard_set = false;
+  bool began = false, have_candidates = false, have_result = false;
+  Pose0 pose0{};
+  AccumPlan plan{};
+  int plan_P = -1; int64_t plan_B = -1; int plan_K = -1;
+
+  DevBuf<double> src, tgt, tx, ty, tz, pool_d, cand_d2, table, init_pose, R, t, Rtot, pose_out, sums, partial, work,
+      stats, trH, trb, trN, trphi, trh;
+  DevBuf<int32_t> pool_i, cand_idx, trcorr;
+  DevBuf<float> history;
+  DevBuf<int> ctl;
+  int hist_I = 0, hist_P = 0;
+  double gpu_ms[3] = {0, 0, 0};
+  bool timing_valid = false;
+};
+
+#define CTX_CHECK(ctx)                         \
+  do {                                         \
+    if (!(ctx)) return SVNICP_ERR_INVALID;     \
+  } while (0)
+
+static int fail(svnicp_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_error = msg;
+  return code;
+}
+#define HIPCHK(c, expr)                                                                          \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      return fail((c), _e == hipErrorOutOfMemory ? SVNICP_ERR_NOMEM : SVNICP_ERR_HIP,           \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                            \
+  } while (0)
+
+static int bind(svnicp_ctx* c) {
+  HIPCHK(c, hipSetDevice(c->device));
+  return 0;
+}
+
+extern "C" {
+
+int svnicp_abi_version(void) { return SVNICP_ABI_VERSION; }
+
+const char* svnicp_last_error(const svnicp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int svnicp_create(const svnicp_params* params, int device, const double* init_pose6xP, int P, svnicp_ctx** out) {
+  if (!params || !out) return fail(nullptr, SVNICP_ERR_INVALID, "svnicp_create: null argument");
+  if (params->struct_size != (int32_t)sizeof(svnicp_params))
+    return fail(nullptr, SVNICP_ERR_INVALID, "svnicp_create: svnicp_params.struct_size mismatch");
+  if (params->iterations < 0 || params->knn_count < 1)
+    return fail(nullptr, SVNICP_ERR_INVALID, "svnicp_create: iterations >= 0 and knn_count >= 1 required");
+  if (params->mode != SVNICP_MODE_SVN && params->mode != SVNICP_MODE_SVGD)
+    return fail(nullptr, SVNICP_ERR_INVALID, "svnicp_create: unknown mode");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, SVNICP_ERR_NO_DEVICE, "svnicp_create: no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(nullptr, SVNICP_ERR_INVALID, "svnicp_create: bad device ordinal");
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return fail(nullptr, SVNICP_ERR_HIP, "svnicp_create: hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, SVNICP_ERR_NO_DEVICE,
+                std::string("svnicp_create: device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+  svnicp_ctx* c = new svnicp_ctx();
+  c->prm = *params;
+  c->device = device;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->K = params->knn_count;
+  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  std::memcpy(c->pose0.R0, I3, sizeof I3);  // SVGDICP.cpp:38-39
+  c->pose0.t0[0] = c->pose0.t0[1] = c->pose0.t0[2] = 0.0;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return fail(nullptr, SVNICP_ERR_HIP, "svnicp_create: hipStreamCreate failed");
+  }
+  c->stream = c->own_stream;
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(nullptr, SVNICP_ERR_HIP, "hipEventCreate failed"); }
+  if (c->ctl.ensure(4) != hipSuccess) { delete c; return fail(nullptr, SVNICP_ERR_NOMEM, "hipMalloc failed"); }
+  *out = c;
+  if (init_pose6xP) {
+    int rc = svnicp_set_particles(c, init_pose6xP, P);
+    if (rc != 0) { g_create_error = c->err; svnicp_destroy(c); *out = nullptr; return rc; }
+  }
+  return SVNICP_OK;
+}
+
+void svnicp_destroy(svnicp_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  DevBuf<double>* dbl[] = {&c->src, &c->tgt, &c->tx, &c->ty, &c->tz, &c->pool_d, &c->cand_d2, &c->table,
+                           &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
+                           &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
+  for (auto* b : dbl) b->release();
+  c->pool_i.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int svnicp_set_stream(svnicp_ctx* c, void* hip_stream) {
+  CTX_CHECK(c);
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return SVNICP_OK;
+}
+
+int svnicp_synchronize(svnicp_ctx* c) {
+  CTX_CHECK(c);
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SVNICP_OK;
+}
+
+int svnicp_set_clouds(svnicp_ctx* c, const double* src, int64_t B, const double* tgt, int64_t M, int mem_kind) {
+  CTX_CHECK(c);
+  if (!src || !tgt || B < 1 || M < 1) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_clouds: need B >= 1, M >= 1");
+  if (M > 0x7fffffffLL || B > 0x7fffffffLL) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_clouds: cloud too large");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, c->src.ensure((size_t)B * 3));
+  HIPCHK(c, c->tgt.ensure((size_t)M * 3));
+  const hipMemcpyKind kind = mem_kind == SVNICP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(c, hipMemcpyAsync(c->src.p, src, (size_t)B * 24, kind, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->tgt.p, tgt, (size_t)M * 24, kind, c->stream));
+  c->B = B; c->M = M; c->Mp = knn_padded_targets(M);
+  HIPCHK(c, c->tx.ensure((size_t)c->Mp));
+  HIPCHK(c, c->ty.ensure((size_t)c->Mp));
+  HIPCHK(c, c->tz.ensure((size_t)c->Mp));
+  HIPCHK(c, launch_targets_soa(c->tgt.p, M, c->Mp, c->tx.p, c->ty.p, c->tz.p, c->stream));
+  if (mem_kind != SVNICP_MEM_DEVICE) HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse its host buffers
+  c->clouds_set = true;
+  c->have_candidates = false;
+  return SVNICP_OK;
+}
+
+int svnicp_set_particles(svnicp_ctx* c, const double* init, int P) {
+  CTX_CHECK(c);
+  if (!init || P < 1) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_particles: need P >= 1");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, c->init_pose.ensure((size_t)P * 6));
+  HIPCHK(c, c->R.ensure((size_t)P * 9));
+  HIPCHK(c, c->t.ensure((size_t)P * 3));
+  HIPCHK(c, c->Rtot.ensure((size_t)P * 12));
+  HIPCHK(c, c->pose_out.ensure((size_t)P * 6));
+  HIPCHK(c, c->sums.ensure((size_t)P * kNSums));
+  HIPCHK(c, c->stats.ensure((size_t)48 + P));
+  HIPCHK(c, c->work.ensure(update_workspace_doubles(P)));
+  HIPCHK(c, hipMemcpyAsync(c->init_pose.p, init, (size_t)P * 48, hipMemcpyHostToDevice, c->stream));
+  const bool first = !c->particles_set || P != c->P;
+  c->P = P;
+  if (!c->shard_set || first) { c->p_lo = 0; c->p_hi = P; c->shard_set = false; }
+  // ctor semantics: pose_particles_ is formed from the initial pose (SVNICP.cpp:36-37, SVGDICP.cpp:33-35);
+  // add_cloud semantics: R_, t_ are reset, pose_particles_ is left alone (SVGDICP.cpp:46-62)
+  HIPCHK(c, launch_init_particles(c->init_pose.p, P, c->pose0, c->prm.mode, c->R.p, c->t.p, c->Rtot.p, c->pose_out.p,
+                                  (first || c->prm.mode == SVNICP_MODE_SVN) ? 1 : 0, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->particles_set = true;
+  c->particles_dirty = true;
+  return SVNICP_OK;
+}
+
+int svnicp_set_initial_mean(svnicp_ctx* c, const double R0[9], const double t0[3]) {
+  CTX_CHECK(c);
+  if (!R0 || !t0) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_initial_mean: null argument");
+  std::memcpy(c->pose0.R0, R0, 9 * sizeof(double));
+  std::memcpy(c->pose0.t0, t0, 3 * sizeof(double));
+  c->have_candidates = false;
+  return SVNICP_OK;
+}
+
+int svnicp_set_k(svnicp_ctx* c, int k) {
+  CTX_CHECK(c);
+  if (k < 1) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_k: k >= 1 required");
+  c->K = k;
+  c->have_candidates = false;
+  return SVNICP_OK;
+}
+
+int svnicp_set_max_dist(svnicp_ctx* c, double md) {
+  CTX_CHECK(c);
+  c->prm.max_dist = md;
+  return SVNICP_OK;
+}
+
+int svnicp_set_shard(svnicp_ctx* c, int p_lo, int p_hi) {
+  CTX_CHECK(c);
+  if (!c->particles_set || p_lo < 0 || p_hi > c->P || p_lo > p_hi)
+    return fail(c, SVNICP_ERR_INVALID, "svnicp_set_shard: need 0 <= p_lo <= p_hi <= P after svnicp_set_particles");
+  c->p_lo = p_lo; c->p_hi = p_hi; c->shard_set = true;
+  return SVNICP_OK;
+}
+
+int svnicp_align_begin(svnicp_ctx* c) {
+  CTX_CHECK(c);
+  if (!c->clouds_set || !c->particles_set)
+    return fail(c, SVNICP_ERR_INVALID, "svnicp_align: svnicp_set_clouds and svnicp_set_particles must come first");
+  if (c->prm.mode == SVNICP_MODE_SVGD)
+    return fail(c, SVNICP_ERR_INVALID, "svnicp_align: SVGD mode is not built yet in this round (SVN mode only)");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  const int I = c->prm.iterations, P = c->P;
+  const int64_t B = c->B;
+  c->S = knn_pool_size(c->K);
+  HIPCHK(c, c->pool_d.ensure((size_t)B * c->S));
+  HIPCHK(c, c->pool_i.ensure((size_t)B * c->S));
+  HIPCHK(c, c->cand_idx.ensure((size_t)B * c->K));
+  HIPCHK(c, c->cand_d2.ensure((size_t)B * c->K));
+  HIPCHK(c, c->table.ensure((size_t)B * c->K * 3));
+  HIPCHK(c, c->history.ensure((size_t)(I > 0 ? I : 1) * 6 * P));
+  c->hist_I = I; c->hist_P = P;
+  const int nshard = c->p_hi - c->p_lo;
+  if (nshard > 0) {
+    c->plan = plan_accumulate(nshard, B, c->K, c->num_cus);
+    HIPCHK(c, c->partial.ensure((size_t)c->plan.grid_x * c->plan.Ppad * kNSums));
+  }
+  if (c->prm.record_trace) {
+    HIPCHK(c, c->trcorr.ensure((size_t)I * P * B));
+    HIPCHK(c, c->trH.ensure((size_t)I * P * 36));
+    HIPCHK(c, c->trb.ensure((size_t)I * P * 6));
+    HIPCHK(c, c->trN.ensure((size_t)I * P * 6));
+    HIPCHK(c, c->trphi.ensure((size_t)I * P * 6));
+    HIPCHK(c, c->trh.ensure((size_t)I + 1));
+    HIPCHK(c, hipMemsetAsync(c->trcorr.p, 0xff, (size_t)I * P * B * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->trH.p, 0, (size_t)I * P * 36 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->trb.p, 0, (size_t)I * P * 6 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->trN.p, 0, (size_t)I * P * 6 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->trphi.p, 0, (size_t)I * P * 6 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->trh.p, 0, ((size_t)I + 1) * 8, c->stream));
+  }
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const int ctl_init[4] = {0, I, 0, 0};  // stop flag, finish_iter (SVGDICP.cpp:42)
+  HIPCHK(c, hipMemcpyAsync(c->ctl.p, ctl_init, sizeof ctl_init, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->history.p, 0, (size_t)(I > 0 ? I : 1) * 6 * P * sizeof(float), c->stream));  // SVGDICP.cpp:172-174
+  // total pose of iteration 0 from the CURRENT R_, t_ and R0, t0 (SVNICP.cpp:58-59)
+  HIPCHK(c, launch_init_particles(c->init_pose.p, P, c->pose0, 2, c->R.p, c->t.p, c->Rtot.p, c->pose_out.p, 0,
+                                  c->stream));
+  c->particles_dirty = false;
+  c->began = true;
+  c->have_result = false;
+  c->timing_valid = false;
+  return SVNICP_OK;
+}
+
+int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
+  CTX_CHECK(c);
+  if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_stage_candidates: call svnicp_align_begin first");
+  if (b_lo < 0 || b_hi > c->B || b_lo > b_hi) return fail(c, SVNICP_ERR_INVALID, "svnicp_stage_candidates: bad row range");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  KnnArgs a{};
+  a.src = c->src.p; a.pose = c->pose0; a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p;
+  a.M = c->M; a.Mp = c->Mp; a.b_lo = b_lo; a.b_hi = b_hi; a.K = c->K; a.S = c->S;
+  a.pool_d = c->pool_d.p; a.pool_i = c->pool_i.p; a.out_idx = c->cand_idx.p; a.out_d2 = c->cand_d2.p;
+  HIPCHK(c, launch_knn_topk(a, c->stream));
+  return SVNICP_OK;
+}
+
+int svnicp_build_candidate_table(svnicp_ctx* c) {
+  CTX_CHECK(c);
+  if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_build_candidate_table: call svnicp_align_begin first");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, launch_build_table(c->cand_idx.p, c->B * (int64_t)c->K, c->tgt.p, c->table.p, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  c->have_candidates = true;
+  return SVNICP_OK;
+}
+
+int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
+  CTX_CHECK(c);
+  if (!c->began || !c->have_candidates)
+    return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_accumulate: candidates not staged");
+  if (it < 0 || it >= c->prm.iterations) return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_accumulate: bad iteration");
+  const int nshard = c->p_hi - c->p_lo;
+  if (nshard <= 0) return SVNICP_OK;
+  if (bind(c)) return SVNICP_ERR_HIP;
+  AccumArgs a{};
+  a.src = c->src.p; a.table = c->table.p; a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K;
+  a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
+  a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;
+  HIPCHK(c, launch_accumulate(c->plan, a, c->stream));
+  HIPCHK(c, launch_reduce_partials(c->partial.p, c->plan.grid_x, c->plan.Ppad, c->p_lo, nshard, c->sums.p, c->ctl.p,
+                                   c->stream));
+  return SVNICP_OK;
+}
+
+int svnicp_iter_update(svnicp_ctx* c, int it) {
+  CTX_CHECK(c);
+  if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_update: call svnicp_align_begin first");
+  if (it < 0 || it >= c->prm.iterations) return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_update: bad iteration");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  UpdateArgs u{};
+  u.sums = c->sums.p; u.R = c->R.p; u.t = c->t.p; u.Rtot = c->Rtot.p; u.pose = c->pose0;
+  u.P = c->P; u.iteration = it; u.iterations = c->prm.iterations;
+  u.lr = c->prm.lr; u.conv_thr = c->prm.convergence_threshold;
+  u.check_early_stop = c->prm.check_early_stop; u.full_grad = c->prm.svn_full_grad;
+  u.work = c->work.p; u.history = c->history.p; u.pose_out = c->pose_out.p; u.ctl = c->ctl.p;
+  if (c->prm.record_trace) {
+    u.trH = c->trH.p + (size_t)it * c->P * 36; u.trb = c->trb.p + (size_t)it * c->P * 6;
+    u.trN = c->trN.p + (size_t)it * c->P * 6; u.trphi = c->trphi.p + (size_t)it * c->P * 6; u.trh = c->trh.p + it;
+  }
+  HIPCHK(c, launch_update(u, c->stream));
+  return SVNICP_OK;
+}
+
+int svnicp_finish(svnicp_ctx* c) {
+  CTX_CHECK(c);
+  if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_finish: call svnicp_align_begin first");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  StatsArgs s{c->pose_out.p, c->P, c->prm.mode, c->stats.p};
+  HIPCHK(c, launch_stats(s, c->stream));
+  c->have_result = true;
+  c->timing_valid = true;
+  return SVNICP_OK;
+}
+
+int svnicp_stopped(svnicp_ctx* c) {
+  CTX_CHECK(c);
+  if (bind(c)) return SVNICP_ERR_HIP;
+  int v[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(v, c->ctl.p, sizeof v, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return v[0] ? 1 : 0;
+}
+
+void* svnicp_candidates_devptr(svnicp_ctx* c) { return c ? (void*)c->cand_idx.p : nullptr; }
+void* svnicp_sums_devptr(svnicp_ctx* c) { return c ? (void*)c->sums.p : nullptr; }
+
+int svnicp_align_async(svnicp_ctx* c) {
+  CTX_CHECK(c);
+  int rc = svnicp_align_begin(c);
+  if (rc) return rc;
+  if ((rc = svnicp_stage_candidates(c, 0, c->B))) return rc;
+  if ((rc = svnicp_build_candidate_table(c))) return rc;
+  for (int it = 0; it < c->prm.iterations; ++it) {
+    if ((rc = svnicp_iter_accumulate(c, it))) return rc;
+    if ((rc = svnicp_iter_update(c, it))) return rc;
+  }
+  return svnicp_finish(c);
+}
+
+int svnicp_align(svnicp_ctx* c) {
+  CTX_CHECK(c);
+  if (c->shard_set && (c->p_lo != 0 || c->p_hi != c->P))
+    return fail(c, SVNICP_ERR_INVALID, "svnicp_align: a particle shard is set; drive the split-phase calls instead");
+  int rc = svnicp_align_async(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SVNICP_ALIGN_SUCCESS;
+}
+
+static int fetch(svnicp_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SVNICP_OK;
+}
+#define NEED_RESULT(c)                                                                   \
+  do {                                                                                   \
+    CTX_CHECK(c);                                                                        \
+    if (!(c)->have_result) return fail((c), SVNICP_ERR_INVALID, "no registration result yet"); \
+  } while (0)
+
+int svnicp_get_transformation(svnicp_ctx* c, double out6[6]) { NEED_RESULT(c); return fetch(c, out6, c->stats.p, 48); }
+int svnicp_get_distribution(svnicp_ctx* c, double out6[6]) { NEED_RESULT(c); return fetch(c, out6, c->stats.p + 6, 48); }
+int svnicp_get_cov_matrix(svnicp_ctx* c, double out36[36]) { NEED_RESULT(c); return fetch(c, out36, c->stats.p + 12, 288); }
+int svnicp_get_particle_weight(svnicp_ctx* c, double* outP) {
+  NEED_RESULT(c);
+  return fetch(c, outP, c->stats.p + 48, (size_t)c->P * 8);
+}
+int svnicp_get_particles(svnicp_ctx* c, double* out6P) {
+  CTX_CHECK(c);
+  if (!c->particles_set) return fail(c, SVNICP_ERR_INVALID, "no particles set");
+  return fetch(c, out6P, c->pose_out.p, (size_t)c->P * 48);
+}
+int svnicp_get_particle_history(svnicp_ctx* c, float* out) {
+  NEED_RESULT(c);
+  return fetch(c, out, c->history.p, (size_t)c->hist_I * 6 * c->hist_P * sizeof(float));
+}
+
+int svnicp_get_gpu_ms(svnicp_ctx* c, double out3[3]) {
+  NEED_RESULT(c);
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float a = 0, b = 0;
+  HIPCHK(c, hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+  HIPCHK(c, hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+  out3[0] = a; out3[1] = b; out3[2] = (double)a + b;
+  return SVNICP_OK;
+}
+
+int svnicp_get_runtime(svnicp_ctx* c, double out3[3]) {
+  NEED_RESULT(c);
+  double ms[3];
+  int rc = svnicp_get_gpu_ms(c, ms);
+  if (rc) return rc;
+  int v[2];
+  rc = fetch(c, v, c->ctl.p, sizeof v);
+  if (rc) return rc;
+  out3[0] = ms[0] * 1e-3; out3[1] = ms[1] * 1e-3; out3[2] = (double)v[1];
+  return SVNICP_OK;
+}
+
+int svnicp_get_candidates(svnicp_ctx* c, int32_t* out) {
+  CTX_CHECK(c);
+  if (!c->have_candidates) return fail(c, SVNICP_ERR_INVALID, "no candidates yet");
+  return fetch(c, out, c->cand_idx.p, (size_t)c->B * c->K * 4);
+}
+int svnicp_get_candidate_dist2(svnicp_ctx* c, double* out) {
+  CTX_CHECK(c);
+  if (!c->have_candidates) return fail(c, SVNICP_ERR_INVALID, "no candidates yet");
+  return fetch(c, out, c->cand_d2.p, (size_t)c->B * c->K * 8);
+}
+
+int svnicp_get_trace(svnicp_ctx* c, int32_t* corr, double* H, double* b, double* N, double* phi, double* h) {
+  NEED_RESULT(c);
+  if (!c->prm.record_trace) return fail(c, SVNICP_ERR_INVALID, "svnicp_get_trace: params.record_trace was 0");
+  const size_t I = (size_t)c->prm.iterations, P = (size_t)c->P;
+  int rc = 0;
+  if (corr && (rc = fetch(c, corr, c->trcorr.p, I * P * (size_t)c->B * 4))) return rc;
+  if (H && (rc = fetch(c, H, c->trH.p, I * P * 36 * 8))) return rc;
+  if (b && (rc = fetch(c, b, c->trb.p, I * P * 6 * 8))) return rc;
+  if (N && (rc = fetch(c, N, c->trN.p, I * P * 6 * 8))) return rc;
+  if (phi && (rc = fetch(c, phi, c->trphi.p, I * P * 6 * 8))) return rc;
+  if (h && (rc = fetch(c, h, c->trh.p, I * 8))) return rc;
+  return SVNICP_OK;
+}
+
+}  // extern "C"

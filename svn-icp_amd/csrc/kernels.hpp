@@ -1,0 +1,74 @@
+// kernels.hpp — argument blocks and host launchers of the HIP kernels (internal to libsvnicp_hip.so)
+#pragma once
+#include "device_math.hpp"
+
+namespace svnicp {
+
+// ---------------- Stage A (knn_topk.hip) ----------------
+struct KnnArgs {
+  const double* src;  // [B][3] source cloud (un-transformed)
+  Pose0 pose;         // R0, t0
+  const double *tx, *ty, *tz;  // target SoA, padded to Mp with NaN
+  int64_t M, Mp;
+  int64_t b_lo, b_hi;  // query rows handled by this launch
+  int K, S;            // S = pool capacity (power of two >= K + 128)
+  double* pool_d;      // [B][S]
+  int32_t* pool_i;     // [B][S]
+  int32_t* out_idx;    // [B][K]
+  double* out_d2;      // [B][K]
+};
+int knn_pool_size(int K);
+int64_t knn_padded_targets(int64_t M);
+hipError_t launch_targets_soa(const double* tgt, int64_t M, int64_t Mp, double* tx, double* ty, double* tz,
+                              hipStream_t st);
+hipError_t launch_knn_topk(const KnnArgs& a, hipStream_t st);
+hipError_t launch_build_table(const int32_t* idx, int64_t n_entries, const double* tgt, double* table,
+                              hipStream_t st);
+
+// ---------------- Stage B (stein_iter.hip) ----------------
+struct AccumArgs {
+  const double* src;    // [B][3]
+  const double* table;  // [B][K][3] candidate coordinates
+  const double* Rtot;   // [P][12]: R_total row-major (9) + t_total (3)
+  int64_t B;
+  int K, RS;            // RS = LDS row stride in doubles (odd)
+  int p_lo, p_hi;       // particle shard of this GPU
+  int TP;               // source points per LDS tile
+  int tiles_per_block;
+  int64_t n_tiles;
+  int Ppad;             // padded shard size = gridDim.y * particles per workgroup
+  double max_dist;
+  double* partial;      // [gridDim.x][Ppad][kNSums]
+  const int* ctl;       // ctl[0] = stop flag
+  int32_t* corr;        // optional trace [P][B] (this iteration), or nullptr
+};
+struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS; int64_t n_tiles; size_t smem; };
+AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus);
+hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st);
+hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles,
+                                  double* sums, const int* ctl, hipStream_t st);
+
+// ---------------- particle update (particle_update.hip) ----------------
+struct UpdateArgs {
+  const double* sums;  // [P][kNSums] (all particles)
+  double* R;           // [P][9]
+  double* t;           // [P][3]
+  double* Rtot;        // [P][12]
+  Pose0 pose;
+  int P, iteration, iterations;
+  double lr, conv_thr;
+  int check_early_stop, full_grad;
+  double* work;        // workspace, see update_workspace_doubles()
+  float* history;      // [I][6][P]
+  double* pose_out;    // [6][P]
+  int* ctl;            // [0] stop flag, [1] finish_iter
+  double *trH, *trb, *trN, *trphi, *trh;  // optional traces (per-iteration slices) or nullptr
+};
+size_t update_workspace_doubles(int P);
+hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose, int mode, double* R, double* t,
+                                 double* Rtot, double* pose_out, int refresh_pose, hipStream_t st);
+hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
+struct StatsArgs { const double* pose; int P; int mode; double* out; /* mean6,var6,cov36,weightsP */ };
+hipError_t launch_stats(const StatsArgs& a, hipStream_t st);
+
+}  // namespace svnicp

@@ -1,0 +1,386 @@
+// particle_update.hip — the small per-iteration Stein step on the particle set, one workgroup.
+//
+// Replaces (SVN mode) the tail of SVNICP::stein_align per iteration (src/core/SVNICP.cpp:71-107):
+//   Newton_grad_right's finalisation H + 1e-6·I, linalg::solve (SVNICP.cpp:149-162),
+//   rotm_to_ypr_tensor / to_rotation_tensor (:166-215), rbf_hessian_kernel incl. torch::median (:254-266),
+//   svgd_grad (:218-227) or svn_full_grad (:229-252), pose_update (:268-279), the early-stop test
+//   (:95-101, evaluated on the device: no per-iteration host sync) and the particle history (:103-107).
+// In the multi-GPU layout every GPU runs this kernel redundantly on ALL particles after the
+// all-gather of the 22 raw sums per particle; identical inputs + identical code ⇒ identical state.
+#include "kernels.hpp"
+
+namespace svnicp {
+
+namespace {
+
+constexpr int UT = 1024;  // threads of the update workgroup
+
+// workspace layout (doubles): H[P][36] b[P][6] N[P][6] x[P][6] phi[P][6] sq[P][P]
+struct Work {
+  double *H, *b, *N, *x, *phi, *sq;
+  __device__ Work(double* w, int P) {
+    H = w; b = H + (size_t)P * 36; N = b + (size_t)P * 6; x = N + (size_t)P * 6; phi = x + (size_t)P * 6;
+    sq = phi + (size_t)P * 6;
+  }
+};
+
+// H (6x6) and b (6) of one particle from its 22 raw sums and Rc = R0·R  (see stein_iter.hip)
+__device__ void finalize_Hb(const double* s, const double* Rc, double* H, double* b) {
+  const double sw = s[0];
+  const double a0 = s[1], a1 = s[2], a2 = s[3];
+  const double xx = s[4], xy = s[5], xz = s[6], yy = s[7], yz = s[8], zz = s[9];
+  const double tr = xx + yy + zz;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) H[i] = 0.0;
+  H[0] = H[7] = H[14] = sw;                      // Σ w·I
+  // top-right −Σw·ŝ, bottom-left +Σw·ŝ with ŝ = [[0,−s2,s1],[s2,0,−s0],[−s1,s0,0]]
+  H[0 * 6 + 4] = a2;  H[0 * 6 + 5] = -a1;
+  H[1 * 6 + 3] = -a2; H[1 * 6 + 5] = a0;
+  H[2 * 6 + 3] = a1;  H[2 * 6 + 4] = -a0;
+  H[3 * 6 + 1] = -a2; H[3 * 6 + 2] = a1;
+  H[4 * 6 + 0] = a2;  H[4 * 6 + 2] = -a0;
+  H[5 * 6 + 0] = -a1; H[5 * 6 + 1] = a0;
+  // bottom-right Σw(‖s‖²I − ssᵀ)
+  H[3 * 6 + 3] = tr - xx; H[3 * 6 + 4] = -xy;     H[3 * 6 + 5] = -xz;
+  H[4 * 6 + 3] = -xy;     H[4 * 6 + 4] = tr - yy; H[4 * 6 + 5] = -yz;
+  H[5 * 6 + 3] = -xz;     H[5 * 6 + 4] = -yz;     H[5 * 6 + 5] = tr - zz;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) H[7 * i] += 1e-6;  // SVNICP.cpp:153
+  // b_t = Rcᵀ Σwe ; b_r = vee-part of G = Rcᵀ·C, C[i][j] = Σ (we)_i s_j
+  mat3T_vec(Rc, s + 10, b);
+  double G[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G[3 * i + j] = Rc[i] * s[13 + j] + Rc[3 + i] * s[16 + j] + Rc[6 + i] * s[19 + j];
+  b[3] = G[7] - G[5];  // s_y u_z − s_z u_y  with u_i s_j = G[i][j]
+  b[4] = G[2] - G[6];
+  b[5] = G[3] - G[1];
+}
+
+__device__ __forceinline__ unsigned int block_scan_incl_256(unsigned int v, unsigned int* tmp, int tid) {
+  // Hillis–Steele inclusive scan over threads 0..255 (all UT threads reach the barriers)
+  for (int off = 1; off < 256; off <<= 1) {
+    if (tid < 256) tmp[tid] = v;
+    __syncthreads();
+    if (tid < 256 && tid >= off) v += tmp[tid - off];
+    __syncthreads();
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
+  if (a.ctl[0]) return;
+  const int tid = threadIdx.x;
+  const int P = a.P;
+  Work w(a.work, P);
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int scan_tmp[256];
+  __shared__ unsigned long long sel_prefix;
+  __shared__ unsigned int sel_rank;
+  __shared__ int nan_flag;
+  __shared__ double sh_h;
+  __shared__ double sh_Hinv[36];
+  __shared__ double sh_Hmean[36];
+  __shared__ double sh_norm[UT / kWave];
+
+  // ---- 1. per particle: H, b, Newton step, x = [t ; Log R] ----
+  for (int p = tid; p < P; p += UT) {
+    double Rc[9], H[36], b[6], LU[36], x6[6];
+    int piv[6];
+    mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
+    finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; }
+    const bool ok = lu6(LU, piv);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x6[i] = b[i];
+    lu6_solve(LU, piv, x6);                                   // SVNICP.cpp:162
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      w.b[p * 6 + i] = b[i];
+      w.N[p * 6 + i] = ok ? x6[i] : __builtin_nan("");
+    }
+    double lg[3];
+    so3_log(a.R + 9 * p, lg);                                 // SVNICP.cpp:74-77
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { w.x[p * 6 + i] = a.t[3 * p + i]; w.x[p * 6 + 3 + i] = lg[i]; }
+  }
+  if (tid == 0) { nan_flag = 0; sel_prefix = 0ull; sel_rank = (unsigned int)(((size_t)P * P - 1) / 2); sh_h = __builtin_nan(""); }
+  __syncthreads();
+
+  if (P > 1) {
+    // ---- 2. pairwise squared distances + exact lower median (torch::median, SVNICP.cpp:257-262) ----
+    const int n = P * P;
+    for (int e = tid; e < n; e += UT) {
+      const int i = e / P, j = e - i * P;
+      double s = 0.0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { const double df = w.x[i * 6 + d] - w.x[j * 6 + d]; s += df * df; }
+      w.sq[e] = s;
+      if (s != s) nan_flag = 1;
+    }
+    __syncthreads();
+    // radix select on the (non-negative) f64 bit patterns, 8 bits per pass, MSB first
+    for (int pass = 7; pass >= 0; --pass) {
+      const int shift = pass * 8;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const unsigned long long pre = sel_prefix;
+      for (int e = tid; e < n; e += UT) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(w.sq[e]);
+        if (pass == 7 || (key >> (shift + 8)) == pre) atomicAdd(&hist[(key >> shift) & 255ull], 1u);
+      }
+      __syncthreads();
+      const unsigned int c = tid < 256 ? hist[tid] : 0u;
+      const unsigned int incl = block_scan_incl_256(c, scan_tmp, tid);
+      const unsigned int rank = sel_rank;
+      __syncthreads();
+      if (tid < 256 && incl > rank && (incl - c) <= rank) {
+        sel_prefix = (pre << 8) | (unsigned long long)tid;
+        sel_rank = rank - (incl - c);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const double med = nan_flag ? __builtin_nan("") : __longlong_as_double((long long)sel_prefix);
+      sh_h = med / log((double)(P + 1));                      // SVNICP.cpp:262
+    }
+    if (!a.full_grad) {                                       // Hessian_mean, SVNICP.cpp:85
+      if (tid < 36) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) s += w.H[(size_t)p * 36 + tid];
+        sh_Hmean[tid] = s / P;
+      }
+    }
+    __syncthreads();
+    if (!a.full_grad && tid == 0) {                           // linalg::inv, SVNICP.cpp:225
+      double LU[36], col[6];
+      int piv[6];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
+      const bool ok = lu6(LU, piv);
+      for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = (r == c) ? 1.0 : 0.0;
+        lu6_solve(LU, piv, col);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sh_Hinv[6 * r + c] = ok ? col[r] : __builtin_nan("");
+      }
+    }
+    __syncthreads();
+    const double h = sh_h;
+    // ---- 3. Stein direction per particle ----
+    for (int i = 0; i < P; i += UT) {
+      const int pi = i + tid;
+      if (pi >= P) continue;
+      double xi[6];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) xi[d] = w.x[pi * 6 + d];
+      if (!a.full_grad) {                                     // svgd_grad, SVNICP.cpp:218-227
+        double g[6] = {0, 0, 0, 0, 0, 0}, kn[6] = {0, 0, 0, 0, 0, 0}, ks = 0.0;
+        for (int j = 0; j < P; ++j) {
+          const double k = exp(-w.sq[(size_t)j * P + pi] / h);  // sq is exactly symmetric
+#pragma unroll
+          for (int d = 0; d < 6; ++d) {
+            g[d] += (xi[d] - w.x[j * 6 + d]) * k;
+            kn[d] += k * (-w.N[j * 6 + d]);
+          }
+          ks += k;
+        }
+#pragma unroll
+        for (int d = 0; d < 6; ++d) g[d] = 2 / h * g[d];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double hg = 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) hg += sh_Hinv[6 * r + c] * g[c];
+          w.phi[pi * 6 + r] = (kn[r] + hg) / ks;
+        }
+      } else {                                                // svn_full_grad, SVNICP.cpp:229-252
+        double Hm[36], u[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 36; ++e) Hm[e] = 0.0;
+        for (int j = 0; j < P; ++j) {
+          const double k = exp(-w.sq[(size_t)j * P + pi] / h);
+          double g[6];
+#pragma unroll
+          for (int d = 0; d < 6; ++d) g[d] = 2 / h * ((xi[d] - w.x[j * 6 + d]) * k);
+          const double k2 = k * k;
+          const double* Hj = w.H + (size_t)j * 36;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Hm[6 * r + c] += k2 * Hj[6 * r + c] + g[r] * g[c];
+            u[r] += k * (-w.b[j * 6 + r]) + g[r];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 36; ++e) Hm[e] /= P;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) u[r] /= P;
+        int piv[6];
+        const bool ok = lu6(Hm, piv);
+        double out[6] = {0, 0, 0, 0, 0, 0};
+        // inv(Hm)·u column by column (the reference forms the inverse, then multiplies)
+        for (int c = 0; c < 6; ++c) {
+          double col[6];
+#pragma unroll
+          for (int r = 0; r < 6; ++r) col[r] = (r == c) ? 1.0 : 0.0;
+          lu6_solve(Hm, piv, col);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) out[r] += col[r] * u[c];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) w.phi[pi * 6 + r] = ok ? a.lr * out[r] : __builtin_nan("");
+      }
+    }
+  } else {
+    if (tid == 0)
+      for (int d = 0; d < 6; ++d) w.phi[d] = -w.N[d];         // SVNICP.cpp:89
+  }
+  __syncthreads();
+
+  // ---- 4. traces (tests only) ----
+  if (a.trH) {
+    for (int e = tid; e < P * 36; e += UT) a.trH[e] = w.H[e];
+    for (int e = tid; e < P * 6; e += UT) { a.trb[e] = w.b[e]; a.trN[e] = w.N[e]; a.trphi[e] = w.phi[e]; }
+    if (tid == 0) *a.trh = sh_h;
+  }
+
+  // ---- 5. pose update (SVNICP.cpp:268-279) + early stop statistic ----
+  double my_norm = 0.0;
+  for (int p = tid; p < P; p += UT) {
+    double phi[6], dR[9], Jl[9], dt[3], Rn[9], Rdt[3], Ro[9];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) phi[d] = w.phi[p * 6 + d];
+    so3_exp(phi + 3, dR, Jl);
+    mat3_vec(Jl, phi, dt);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ro[i] = a.R[9 * p + i];
+    mat3_mul(Ro, dR, Rn);
+    mat3_vec(Rn, dt, Rdt);                                    // uses the UPDATED R (:277-278)
+    double tn[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tn[i] = Rdt[i] + a.t[3 * p + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.R[9 * p + i] = Rn[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.t[3 * p + i] = tn[i];
+    // next iteration's total pose (SVNICP.cpp:58-59)
+    double Rt[9], tt[3];
+    mat3_mul(a.pose.R0, Rn, Rt);
+    mat3_vec(a.pose.R0, tn, tt);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.Rtot[12 * p + i] = Rt[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.Rtot[12 * p + 9 + i] = a.pose.t0[i] + tt[i];
+    double n2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) n2 += phi[d] * phi[d];
+    my_norm += sqrt(n2);
+    // pose_particles_ = [t ; Log R] (SVNICP.cpp:103-106)
+    double lg[3];
+    so3_log(Rn, lg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a.pose_out[i * P + p] = tn[i]; a.pose_out[(3 + i) * P + p] = lg[i]; }
+  }
+  bool stop = false;
+  if (a.check_early_stop) {  // block-uniform
+    for (int off = 32; off > 0; off >>= 1) my_norm += __shfl_xor(my_norm, off, kWave);
+    if ((tid & 63) == 0) sh_norm[tid >> 6] = my_norm;
+    __syncthreads();
+    double m = 0.0;
+    for (int i = 0; i < UT / kWave; ++i) m += sh_norm[i];
+    m /= P;
+    // torch::lt(f64 0-dim, f32 1-dim) promotes to float32 (SVNICP.cpp:42,96-97)
+    stop = (float)m < (float)a.conv_thr;
+  }
+  if (stop) {
+    if (tid == 0) { a.ctl[0] = 1; a.ctl[1] = a.iteration + 1; }
+    return;  // history row of the stopping epoch stays zero (break before :103-107)
+  }
+  __syncthreads();
+  for (int e = tid; e < 6 * P; e += UT) a.history[(size_t)a.iteration * 6 * P + e] = (float)a.pose_out[e];
+}
+
+// constructor / add_cloud: R = Exp(r), t, total pose (SVNICP.cpp:20-38, SVGDICP.cpp:46-62)
+__global__ void k_init_particles(const double* __restrict__ init, int P, Pose0 pose, int mode, double* R, double* t,
+                                 double* Rtot, double* pose_out, int refresh_pose) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double r[3] = {0, 0, 0}, tv[3], Rm[9];
+  if (mode == 2) {  // keep the current R_, t_: only the total pose is recomputed
+    for (int i = 0; i < 9; ++i) Rm[i] = R[9 * p + i];
+    for (int i = 0; i < 3; ++i) tv[i] = t[3 * p + i];
+  } else {
+    r[0] = init[3 * P + p]; r[1] = init[4 * P + p]; r[2] = init[5 * P + p];
+    tv[0] = init[p]; tv[1] = init[P + p]; tv[2] = init[2 * P + p];
+    if (mode == 0) so3_exp(r, Rm, nullptr); else euler_to_R(r[0], r[1], r[2], Rm);
+  }
+  double Rt[9], tt[3];
+  mat3_mul(pose.R0, Rm, Rt);
+  mat3_vec(pose.R0, tv, tt);
+  for (int i = 0; i < 9; ++i) { R[9 * p + i] = Rm[i]; Rtot[12 * p + i] = Rt[i]; }
+  for (int i = 0; i < 3; ++i) { t[3 * p + i] = tv[i]; Rtot[12 * p + 9 + i] = pose.t0[i] + tt[i]; }
+  if (refresh_pose) {
+    double lg[3];
+    if (mode == 0) so3_log(Rm, lg); else { lg[0] = r[0]; lg[1] = r[1]; lg[2] = r[2]; }
+    for (int i = 0; i < 3; ++i) { pose_out[i * P + p] = tv[i]; pose_out[(3 + i) * P + p] = lg[i]; }
+  }
+}
+
+// get_transformation / get_distribution / get_cov_matrix / get_particle_weight
+// (SVNICP.cpp:281-308; SVGDICP.cpp:497-524).  out = mean[6] var[6] cov[36] weights[P]
+__global__ void k_stats(StatsArgs a) {
+  const int tid = threadIdx.x;
+  const int P = a.P;
+  __shared__ double mean[6];
+  // SVNICP.cpp:46: torch::ones({P,1}) / P is float32, promoted to f64 in the products
+  const double wsvn = (double)(1.0f / (float)P);
+  if (tid < 6) {
+    double s = 0.0;
+    if (a.mode == 0) { for (int p = 0; p < P; ++p) s += a.pose[tid * P + p] * wsvn; }
+    else { for (int p = 0; p < P; ++p) s += a.pose[tid * P + p]; s /= P; }
+    mean[tid] = s;
+    a.out[tid] = s;
+  }
+  __syncthreads();
+  if (tid < 6) {
+    double s = 0.0;
+    if (a.mode == 0) { for (int p = 0; p < P; ++p) { const double d = a.pose[tid * P + p] - mean[tid]; s += d * d * wsvn; } }
+    else { for (int p = 0; p < P; ++p) { const double d = a.pose[tid * P + p] - mean[tid]; s += d * d; } s /= (P - 1); }
+    a.out[6 + tid] = s;
+  }
+  if (tid < 36) {
+    const int r = tid / 6, c = tid % 6;
+    double s = 0.0;
+    const double wgt = a.mode == 0 ? wsvn : 1.0;
+    for (int p = 0; p < P; ++p) s += wgt * ((a.pose[r * P + p] - mean[r]) * (a.pose[c * P + p] - mean[c]));
+    a.out[12 + tid] = a.mode == 0 ? s : s / P;
+  }
+  for (int p = tid; p < P; p += blockDim.x) a.out[48 + p] = a.mode == 0 ? wsvn : 1.0;
+}
+
+}  // namespace
+
+size_t update_workspace_doubles(int P) { return (size_t)P * (36 + 6 * 4) + (size_t)P * P + 64; }
+
+hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose, int mode, double* R, double* t,
+                                 double* Rtot, double* pose_out, int refresh_pose, hipStream_t st) {
+  hipLaunchKernelGGL(k_init_particles, dim3((P + 127) / 128), dim3(128), 0, st, init6xP, P, pose, mode, R, t, Rtot,
+                     pose_out, refresh_pose);
+  return hipGetLastError();
+}
+
+hipError_t launch_update(const UpdateArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_particle_update, dim3(1), dim3(UT), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_stats(const StatsArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace svnicp

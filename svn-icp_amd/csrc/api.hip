@@ -60,7 +60,35 @@ struct svnicp_ctx {
   int hist_I = 0, hist_P = 0;
   double gpu_ms[3] = {0, 0, 0};
   bool timing_valid = false;
+  // optional per-kernel-class timing (svnicp_set_profile): event pairs around every launch
+  bool profile = false;
+  std::vector<hipEvent_t> pev;          // pairs: [2*i] start, [2*i+1] stop
+  std::vector<int> pcls;                // kernel class of pair i
+  size_t pused = 0;
 };
+
+enum { KC_KNN = 0, KC_TABLE = 1, KC_ACCUM = 2, KC_REDUCE = 3, KC_UPDATE = 4, KC_COUNT = 5 };
+
+static hipError_t prof_begin(svnicp_ctx* c, int cls) {
+  if (!c->profile) return hipSuccess;
+  if (c->pused * 2 + 2 > c->pev.size()) {
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t e;
+      hipError_t r = hipEventCreate(&e);
+      if (r != hipSuccess) return r;
+      c->pev.push_back(e);
+    }
+    c->pcls.push_back(cls);
+  }
+  c->pcls[c->pused] = cls;
+  return hipEventRecord(c->pev[2 * c->pused], c->stream);
+}
+static hipError_t prof_end(svnicp_ctx* c) {
+  if (!c->profile) return hipSuccess;
+  hipError_t r = hipEventRecord(c->pev[2 * c->pused + 1], c->stream);
+  c->pused += 1;
+  return r;
+}
 
 #define CTX_CHECK(ctx)                         \
   do {                                         \
@@ -142,6 +170,7 @@ void svnicp_destroy(svnicp_ctx* c) {
   for (auto* b : dbl) b->release();
   c->pool_i.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->pev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -273,6 +302,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->trphi.p, 0, (size_t)I * P * 6 * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->trh.p, 0, ((size_t)I + 1) * 8, c->stream));
   }
+  c->pused = 0;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   const int ctl_init[4] = {0, I, 0, 0};  // stop flag, finish_iter (SVGDICP.cpp:42)
   HIPCHK(c, hipMemcpyAsync(c->ctl.p, ctl_init, sizeof ctl_init, hipMemcpyHostToDevice, c->stream));
@@ -296,7 +326,9 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
   a.src = c->src.p; a.pose = c->pose0; a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p;
   a.M = c->M; a.Mp = c->Mp; a.b_lo = b_lo; a.b_hi = b_hi; a.K = c->K; a.S = c->S;
   a.pool_d = c->pool_d.p; a.pool_i = c->pool_i.p; a.out_idx = c->cand_idx.p; a.out_d2 = c->cand_d2.p;
+  HIPCHK(c, prof_begin(c, KC_KNN));
   HIPCHK(c, launch_knn_topk(a, c->stream));
+  HIPCHK(c, prof_end(c));
   return SVNICP_OK;
 }
 
@@ -304,7 +336,9 @@ int svnicp_build_candidate_table(svnicp_ctx* c) {
   CTX_CHECK(c);
   if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_build_candidate_table: call svnicp_align_begin first");
   if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, prof_begin(c, KC_TABLE));
   HIPCHK(c, launch_build_table(c->cand_idx.p, c->B * (int64_t)c->K, c->tgt.p, c->table.p, c->stream));
+  HIPCHK(c, prof_end(c));
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   c->have_candidates = true;
   return SVNICP_OK;
@@ -322,9 +356,13 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   a.src = c->src.p; a.table = c->table.p; a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K;
   a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
   a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;
+  HIPCHK(c, prof_begin(c, KC_ACCUM));
   HIPCHK(c, launch_accumulate(c->plan, a, c->stream));
+  HIPCHK(c, prof_end(c));
+  HIPCHK(c, prof_begin(c, KC_REDUCE));
   HIPCHK(c, launch_reduce_partials(c->partial.p, c->plan.grid_x, c->plan.Ppad, c->p_lo, nshard, c->sums.p, c->ctl.p,
                                    c->stream));
+  HIPCHK(c, prof_end(c));
   return SVNICP_OK;
 }
 
@@ -343,7 +381,9 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
     u.trH = c->trH.p + (size_t)it * c->P * 36; u.trb = c->trb.p + (size_t)it * c->P * 6;
     u.trN = c->trN.p + (size_t)it * c->P * 6; u.trphi = c->trphi.p + (size_t)it * c->P * 6; u.trh = c->trh.p + it;
   }
+  HIPCHK(c, prof_begin(c, KC_UPDATE));
   HIPCHK(c, launch_update(u, c->stream));
+  HIPCHK(c, prof_end(c));
   return SVNICP_OK;
 }
 
@@ -443,6 +483,27 @@ int svnicp_get_runtime(svnicp_ctx* c, double out3[3]) {
   rc = fetch(c, v, c->ctl.p, sizeof v);
   if (rc) return rc;
   out3[0] = ms[0] * 1e-3; out3[1] = ms[1] * 1e-3; out3[2] = (double)v[1];
+  return SVNICP_OK;
+}
+
+int svnicp_set_profile(svnicp_ctx* c, int on) {
+  CTX_CHECK(c);
+  c->profile = on != 0;
+  return SVNICP_OK;
+}
+
+int svnicp_get_kernel_ms(svnicp_ctx* c, double* ms5, int32_t* launches5) {
+  NEED_RESULT(c);
+  if (!c->profile) return fail(c, SVNICP_ERR_INVALID, "svnicp_get_kernel_ms: profiling is off (svnicp_set_profile)");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < KC_COUNT; ++i) { ms5[i] = 0.0; launches5[i] = 0; }
+  for (size_t i = 0; i < c->pused; ++i) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->pev[2 * i], c->pev[2 * i + 1]));
+    ms5[c->pcls[i]] += ms;
+    launches5[c->pcls[i]] += 1;
+  }
   return SVNICP_OK;
 }
 

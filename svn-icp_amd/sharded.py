@@ -1,0 +1,169 @@
+"""Particle-sharded registration: one process per GPU, torch.distributed (RCCL over xGMI) for the
+one exchange step the path has.
+
+New functionality — the reference is single process / single GPU.
+Partition: rank r owns particles [r·ceil(P/W), (r+1)·ceil(P/W)) for the heavy per-iteration pass
+(transform → nearest-of-K → Gauss–Newton sums, svnicp_iter_accumulate) and source rows
+[r·ceil(B/W), …) of the candidate search (svnicp_stage_candidates); clouds and the candidate
+table are replicated.  Exchanges:
+  * once per registration: all-gather of the int32 candidate rows [B/W, K];
+  * once per iteration: all-gather of the per-particle record (22 float64 sums = 176 B);
+after which every rank runs the small Stein update redundantly on all P particles
+(svnicp_iter_update) — identical inputs and code, so the replicas stay bit-identical and no
+broadcast or reduction collective is needed.
+
+The compute backend is the HIP library through the split-phase C ABI (HipBackend).  The class
+takes a ``backend`` argument only so that the orchestration can be exercised by the CPU tests
+(world_size 2, gloo) with a test-side backend; the product never constructs anything else and
+HipBackend raises when libsvnicp_hip.so or a gfx950 device is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import binding
+from .solver import SVNICP, SteinICPParam, SteinICPState
+
+
+def shard_range(n: int, world: int, rank: int) -> tuple[int, int]:
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+class _DevView:
+    """Zero-copy torch view of library-owned device memory via __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class HipBackend:
+    """Split-phase driver of libsvnicp_hip.so for one rank (include/svnicp_hip.h, 'split-phase entry points')."""
+
+    record_width = 22
+
+    def __init__(self, param: SteinICPParam, init_pose, device_index: int):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        self.solver = SVNICP(param, init_pose, device=device_index)
+        self._L = binding.load_library()
+        self._h = self.solver.handle
+        # one queue for kernels and collectives: run the library on torch's current stream
+        stream = torch.cuda.current_stream(self.device)
+        self.solver._check(self._L.svnicp_set_stream(self._h, C.c_void_p(stream.cuda_stream)), "svnicp_set_stream")
+
+    def add_cloud(self, src, tgt, init_pose):
+        self.solver.add_cloud(src, tgt, init_pose)
+        self.P, self.B, self.K = self.solver._P, self.solver._B, self.solver._K
+
+    def set_initial_mean(self, pose):
+        self.solver.set_initial_mean(pose)
+
+    def _chk(self, rc, what):
+        self.solver._check(rc, what)
+
+    def set_shard(self, lo, hi):
+        self._chk(self._L.svnicp_set_shard(self._h, lo, hi), "svnicp_set_shard")
+
+    def align_begin(self):
+        self._chk(self._L.svnicp_align_begin(self._h), "svnicp_align_begin")
+
+    def stage_candidates(self, lo, hi):
+        self._chk(self._L.svnicp_stage_candidates(self._h, lo, hi), "svnicp_stage_candidates")
+
+    def candidates_tensor(self):
+        ptr = self._L.svnicp_candidates_devptr(self._h)
+        return self.torch.as_tensor(_DevView(ptr, (self.B, self.K), "<i4"), device=self.device)
+
+    def build_table(self):
+        self._chk(self._L.svnicp_build_candidate_table(self._h), "svnicp_build_candidate_table")
+
+    def iter_accumulate(self, it):
+        self._chk(self._L.svnicp_iter_accumulate(self._h, it), "svnicp_iter_accumulate")
+
+    def records_tensor(self):
+        ptr = self._L.svnicp_sums_devptr(self._h)
+        return self.torch.as_tensor(_DevView(ptr, (self.P, self.record_width), "<f8"), device=self.device)
+
+    def iter_update(self, it):
+        self._chk(self._L.svnicp_iter_update(self._h, it), "svnicp_iter_update")
+
+    def finish(self):
+        self._chk(self._L.svnicp_finish(self._h), "svnicp_finish")
+
+    def stopped(self) -> bool:
+        return bool(self._L.svnicp_stopped(self._h))
+
+    def synchronize(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+
+def _all_gather_rows(dist, group, full, lo, hi, world, rank):
+    """In-place all-gather of row blocks of `full` ([n, w]); block r = rows shard_range(n, world, r)."""
+    import torch
+    n = full.shape[0]
+    per = (n + world - 1) // world
+    if n == per * world:
+        dist.all_gather_into_tensor(full, full[lo:hi].clone() if full.device.type == "cpu" else full[lo:hi], group=group)
+        return
+    # ragged tail: gather padded blocks, then scatter the valid rows back
+    pad = torch.zeros((per,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    pad[: hi - lo] = full[lo:hi]
+    stage = torch.empty((world * per,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    dist.all_gather_into_tensor(stage, pad, group=group)
+    full.copy_(stage[:n])
+
+
+class ShardedSVNICP:
+    """SVNICP with the same call sequence as the single-GPU class, particles sharded over a process group."""
+
+    def __init__(self, param: SteinICPParam, init_pose, group=None, device_index: int | None = None, backend=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.param = param
+        if backend is None:
+            import torch
+            if device_index is None:
+                device_index = torch.cuda.current_device()
+            backend = HipBackend(param, init_pose, device_index)
+        self.be = backend
+
+    def add_cloud(self, src, tgt, init_pose):
+        self.be.add_cloud(src, tgt, init_pose)
+
+    def set_initial_mean(self, pose):
+        self.be.set_initial_mean(pose)
+
+    def stein_align(self) -> SteinICPState:
+        be, W, r = self.be, self.world, self.rank
+        p_lo, p_hi = shard_range(be.P, W, r)
+        b_lo, b_hi = shard_range(be.B, W, r)
+        be.set_shard(p_lo, p_hi)
+        be.align_begin()
+        be.stage_candidates(b_lo, b_hi)
+        if W > 1:
+            _all_gather_rows(self.dist, self.group, be.candidates_tensor(), b_lo, b_hi, W, r)
+        be.build_table()
+        for it in range(int(self.param.iterations)):
+            be.iter_accumulate(it)
+            if W > 1:
+                _all_gather_rows(self.dist, self.group, be.records_tensor(), p_lo, p_hi, W, r)
+            be.iter_update(it)
+            if self.param.check_early_stop and be.stopped():
+                break
+        be.finish()
+        be.synchronize()
+        return SteinICPState.ALIGN_SUCCESS
+
+    def __getattr__(self, name):  # getters of the reference interface
+        if name.startswith("get_"):
+            return getattr(self.be.solver, name)
+        raise AttributeError(name)

@@ -220,6 +220,19 @@ class _SolverBase:
     def get_gpu_ms(self) -> np.ndarray:
         return self._getd("gpu_ms", 3)
 
+    KERNEL_CLASSES = ("k_knn_topk", "k_build_table", "k_stein_accumulate", "k_reduce_partials", "k_particle_update")
+
+    def set_profile(self, on: bool):
+        self._check(self._L.svnicp_set_profile(self._h, int(on)), "svnicp_set_profile")
+
+    def get_kernel_ms(self) -> dict:
+        """{kernel class: (total ms in the last align, launches)} — hipEvents on the library's stream."""
+        ms = np.zeros(5, np.float64)
+        n = np.zeros(5, np.int32)
+        self._check(self._L.svnicp_get_kernel_ms(self._h, ms.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 n.ctypes.data_as(C.POINTER(C.c_int32))), "svnicp_get_kernel_ms")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
+
     def get_candidates(self) -> np.ndarray:
         out = np.zeros((self._B, self._K), np.int32)
         self._check(self._L.svnicp_get_candidates(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))),

@@ -45,6 +45,14 @@ def load_library():
     if not os.path.exists(_LIB_PATH):
         raise SvnIcpError(f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch wheels bundle their own libamdhip64; if the system HIP runtime gets loaded first (through
+    # this library), a later `import torch` binds to it and torch.cuda reports "No HIP GPUs".  Import
+    # torch first so that the whole process shares ONE runtime (torch is only plumbing here: device
+    # memory, streams, torch.distributed — the library itself has no torch dependency).
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
     try:
         L = C.CDLL(_LIB_PATH)
     except OSError as e:  # pragma: no cover

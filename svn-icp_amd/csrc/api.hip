@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,7 +55,7 @@ struct svnicp_ctx {
 
   DevBuf<double> src, tgt, tx, ty, tz, pool_d, cand_d2, table, init_pose, R, t, Rtot, pose_out, sums, partial, work,
       stats, trH, trb, trN, trphi, trh;
-  DevBuf<int32_t> pool_i, cand_idx, trcorr;
+  DevBuf<int32_t> pool_i, cand_idx, trcorr, torig;
   DevBuf<float> history;
   DevBuf<int> ctl;
   int hist_I = 0, hist_P = 0;
@@ -168,7 +169,7 @@ void svnicp_destroy(svnicp_ctx* c) {
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
   for (auto* b : dbl) b->release();
-  c->pool_i.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  c->pool_i.release(); c->torig.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->pev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -202,7 +203,8 @@ int svnicp_set_clouds(svnicp_ctx* c, const double* src, int64_t B, const double*
   HIPCHK(c, c->tx.ensure((size_t)c->Mp));
   HIPCHK(c, c->ty.ensure((size_t)c->Mp));
   HIPCHK(c, c->tz.ensure((size_t)c->Mp));
-  HIPCHK(c, launch_targets_soa(c->tgt.p, M, c->Mp, c->tx.p, c->ty.p, c->tz.p, c->stream));
+  HIPCHK(c, c->torig.ensure((size_t)c->Mp));
+  HIPCHK(c, launch_targets_soa(c->tgt.p, M, c->Mp, c->tx.p, c->ty.p, c->tz.p, c->torig.p, c->stream));
   if (mem_kind != SVNICP_MEM_DEVICE) HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse its host buffers
   c->clouds_set = true;
   c->have_candidates = false;
@@ -323,9 +325,10 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
   if (b_lo < 0 || b_hi > c->B || b_lo > b_hi) return fail(c, SVNICP_ERR_INVALID, "svnicp_stage_candidates: bad row range");
   if (bind(c)) return SVNICP_ERR_HIP;
   KnnArgs a{};
-  a.src = c->src.p; a.pose = c->pose0; a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p;
+  a.src = c->src.p; a.pose = c->pose0; a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p; a.torig = c->torig.p;
   a.M = c->M; a.Mp = c->Mp; a.b_lo = b_lo; a.b_hi = b_hi; a.K = c->K; a.S = c->S;
   a.pool_d = c->pool_d.p; a.pool_i = c->pool_i.p; a.out_idx = c->cand_idx.p; a.out_d2 = c->cand_d2.p;
+  { const char* e = getenv("SVNICP_DBG"); a.dbg = e ? atoi(e) : 0; }
   HIPCHK(c, prof_begin(c, KC_KNN));
   HIPCHK(c, launch_knn_topk(a, c->stream));
   HIPCHK(c, prof_end(c));

@@ -8,7 +8,8 @@ namespace svnicp {
 struct KnnArgs {
   const double* src;  // [B][3] source cloud (un-transformed)
   Pose0 pose;         // R0, t0
-  const double *tx, *ty, *tz;  // target SoA, padded to Mp with NaN
+  const double *tx, *ty, *tz;  // target SoA in permuted order, padded to Mp with NaN
+  const int32_t* torig;        // [Mp] original target index of each slot
   int64_t M, Mp;
   int64_t b_lo, b_hi;  // query rows handled by this launch
   int K, S;            // S = pool capacity (power of two >= K + 128)
@@ -16,11 +17,12 @@ struct KnnArgs {
   int32_t* pool_i;     // [B][S]
   int32_t* out_idx;    // [B][K]
   double* out_d2;      // [B][K]
+  int dbg;             // bring-up experiments only (SVNICP_DBG env): 1 = skip slow path, 2 = skip merges
 };
 int knn_pool_size(int K);
 int64_t knn_padded_targets(int64_t M);
 hipError_t launch_targets_soa(const double* tgt, int64_t M, int64_t Mp, double* tx, double* ty, double* tz,
-                              hipStream_t st);
+                              int32_t* torig, hipStream_t st);
 hipError_t launch_knn_topk(const KnnArgs& a, hipStream_t st);
 hipError_t launch_build_table(const int32_t* idx, int64_t n_entries, const double* tgt, double* table,
                               hipStream_t st);

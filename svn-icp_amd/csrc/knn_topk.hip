@@ -12,6 +12,9 @@
 //    and its running threshold are wave-uniform (LDS broadcast reads).
 //  * the hot loop is 8 f64 VALU ops + 1 compare per pair, no data-dependent work: a pair only
 //    leaves the fast path when d² <= thr (≈ K·ln(M/K) times per query out of M).
+//  * the target stream is visited in a golden-ratio-stride permutation j → (j·A) mod Mp, so every
+//    256-point tile is a uniform sample of the cloud: scan-ordered input would otherwise tighten
+//    the threshold gradually and push ~100× more pairs through the slow path (measured).
 //  * survivors are compacted with ballot/mbcnt into the query's candidate pool (global, L2
 //    resident, touched rarely); when a pool is nearly full the wave bitonic-sorts it in LDS by
 //    (d², idx), keeps the best K and lowers the threshold.  The filter uses '<=' on a
@@ -140,12 +143,13 @@ __global__ __launch_bounds__(256) void k_knn_topk(KnnArgs a) {
         m[t] = __ballot(d[t] <= thr);
         any |= m[t];
       }
-      if (any) {  // wave-uniform slow path
+      if (any && !(a.dbg & 1)) {  // wave-uniform slow path
         const int64_t pool_base = (q0 + q) * (int64_t)S;
         int n = __builtin_amdgcn_readfirstlane(cnt[q]);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           if (m[t]) {
+            if (n > S - kWave && (a.dbg & 2)) n = K;  // DEBUG: drop instead of merging
             if (n > S - kWave) {  // make room for up to 64 new entries
               if (lane == 0) cnt[q] = n;
               wave_sync();
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void k_knn_topk(KnnArgs a) {
             const int pos = n + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
             if ((m[t] >> lane) & 1ull) {
               a.pool_d[pool_base + pos] = d[t];
-              a.pool_i[pool_base + pos] = (int32_t)(tile + t * kWave + lane);
+              a.pool_i[pool_base + pos] = a.torig[tile + t * kWave + lane];  // original target index
             }
             n += __popcll(m[t]);
           }
@@ -183,15 +187,20 @@ __global__ __launch_bounds__(256) void k_knn_topk(KnnArgs a) {
   }
 }
 
-// AoS [M][3] -> SoA tx/ty/tz padded to Mp with NaN (a NaN distance never passes 'd2 <= thr')
-__global__ void k_targets_soa(const double* __restrict__ tgt, int64_t M, int64_t Mp, double* __restrict__ tx,
-                              double* __restrict__ ty, double* __restrict__ tz) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Mp) return;
+// AoS [M][3] -> permuted SoA tx/ty/tz of length Mp: slot j holds target (j·A) mod Mp (A coprime
+// with Mp), or NaN when that index is >= M (a NaN distance never passes 'd2 <= thr')
+__global__ void k_targets_soa(const double* __restrict__ tgt, int64_t M, int64_t Mp, int64_t A,
+                              double* __restrict__ tx, double* __restrict__ ty, double* __restrict__ tz,
+                              int32_t* __restrict__ torig) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Mp) return;
+  const int64_t i = (int64_t)(((unsigned long long)j * (unsigned long long)A) % (unsigned long long)Mp);
   const double nan = __builtin_nan("");
-  tx[i] = i < M ? tgt[3 * i] : nan;
-  ty[i] = i < M ? tgt[3 * i + 1] : nan;
-  tz[i] = i < M ? tgt[3 * i + 2] : nan;
+  const bool in = i < M;
+  tx[j] = in ? tgt[3 * i] : nan;
+  ty[j] = in ? tgt[3 * i + 1] : nan;
+  tz[j] = in ? tgt[3 * i + 2] : nan;
+  torig[j] = (int32_t)i;
 }
 
 // target_batch = index_select(target, sourceKNN_idx) (SVGDICP.cpp:191-193), ONE copy [B][K][3]
@@ -214,11 +223,21 @@ int knn_pool_size(int K) {
 }
 int64_t knn_padded_targets(int64_t M) { return ((M + STEP - 1) / STEP) * STEP; }
 
+static int64_t gcd64(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
+
+int64_t knn_stride(int64_t Mp) {
+  if (Mp <= STEP) return 1;
+  int64_t A = (int64_t)(0.6180339887498949 * (double)Mp) | 1;
+  while (gcd64(A, Mp) != 1) A += 2;
+  return A % Mp;
+}
+
 hipError_t launch_targets_soa(const double* tgt, int64_t M, int64_t Mp, double* tx, double* ty, double* tz,
-                              hipStream_t st) {
+                              int32_t* torig, hipStream_t st) {
   if (Mp <= 0) return hipSuccess;
   const int64_t nb = (Mp + 255) / 256;
-  hipLaunchKernelGGL(k_targets_soa, dim3((unsigned)nb), dim3(256), 0, st, tgt, M, Mp, tx, ty, tz);
+  hipLaunchKernelGGL(k_targets_soa, dim3((unsigned)nb), dim3(256), 0, st, tgt, M, Mp, knn_stride(Mp), tx, ty, tz,
+                     torig);
   return hipGetLastError();
 }
 

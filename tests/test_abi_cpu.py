@@ -1,0 +1,72 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, and refuses to compute without a gfx950 device (no CPU fallback)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.load_library()
+    names = pkg.declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert pkg.abi_version() == 1
+
+
+def test_header_is_plain_c(pkg, tmp_path):
+    src = tmp_path / "t.c"
+    root = os.path.dirname(os.path.dirname(pkg.library_path()))
+    src.write_text('#include "svnicp_hip.h"\nint main(void){svnicp_params p; p.struct_size=(int)sizeof p; return p.struct_size==0;}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src), "-o",
+                           str(tmp_path / "t.o")])
+
+
+def test_params_struct_matches_header(pkg):
+    from svnicp_amd.binding import Params
+    assert C.sizeof(Params) == 56  # 4*int32 + 3*double + 4*int32
+
+
+def test_no_cpu_fallback_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.SvnIcpError) as e:
+        pkg.SVNICP(pkg.SteinICPParam(iterations=1), np.zeros((6, 2)))
+    assert "no HIP device" in str(e.value) or "failed" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    """The product may mention the oracle in comments; it must never include, import, load or run it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r'(#\s*include\s*[<"][^>"]*oracle|^\s*(from|import)\s+\S*oracle|load_oracle|CDLL\([^)]*oracle|dlopen\([^)]*oracle)',
+                     re.M)
+    bad = []
+    for d, _, files in os.walk(os.path.join(root, "svn-icp_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) and pat.search(open(os.path.join(d, f)).read()):
+                bad.append(f)
+    assert not bad, bad
+
+
+def test_initialize_particles_mirror(pkg):
+    ub = np.array(pkg.scans.PARTICLE_UB); lb = np.array(pkg.scans.PARTICLE_LB)
+    assert np.array_equal(pkg.initialize_particles(1, ub, lb), np.zeros((6, 1)))  # ICPUtils.cpp:49-50
+    p = pkg.initialize_particles(100, ub, lb, np.random.default_rng(0))
+    assert p.shape == (6, 100) and np.all(p <= ub[:, None]) and np.all(p >= lb[:, None])
+
+
+def test_scan_generator_is_deterministic(pkg):
+    a = pkg.scans.make_pair(4096, 8192)
+    b = pkg.scans.make_pair(4096, 8192)
+    assert np.array_equal(a.source, b.source) and np.array_equal(a.target, b.target)
+    assert a.source.shape == (4096, 3) and a.target.shape == (8192, 3)
+    assert np.array_equal(a.source, a.source.astype(np.float32).astype(np.float64))  # float32-representable
+    r = np.linalg.norm(a.source, axis=1)
+    assert r.min() >= 1.0 - 1e-6 and r.max() <= 100.0 + 1e-4
+    # first uniform of stream 0 is a fixed constant of the counter-based generator
+    assert abs(pkg.scans.uniform01(0, 1)[0] - pkg.scans.uniform01(0, 3)[0]) == 0

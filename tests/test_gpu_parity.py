@@ -1,0 +1,276 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the golden
+vectors.  Bars (BASELINE.json north_star): correspondence indices bit-exact under brute-force NN,
+final SE(3) pose within 1e-4 m / 1e-4 rad.  The small cases are held to ~1e-9."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import golden_cases, load_golden, oracle_from_golden, POSE_TOL, TIGHT
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip_solver(pkg, init, trace=True, **cfg):
+    prm = pkg.SteinICPParam(iterations=cfg["iterations"], lr=cfg["lr"], max_dist=cfg["max_dist"],
+                            check_early_stop=cfg.get("check_early_stop", False),
+                            convergence_threshold=cfg.get("convergence_threshold", 1e-5), KNN_count=cfg["knn_count"],
+                            SVN_full_grad=cfg.get("svn_full_grad", False), record_trace=trace)
+    return pkg.SVNICP(prm, init, pkg.ParticleWeightOpt())
+
+
+def _compare(s, o, tro, P, strict_pose=TIGHT):
+    n = o.finish_iter() if o.prm.check_early_stop else o.I
+    assert np.array_equal(s.get_candidates().astype(np.int64), o.candidates()), "stage-A indices"
+    assert np.array_equal(s.get_candidate_dist2(), o.candidate_dist2()), "stage-A dist2 bits"
+    tr = s.get_trace()
+    assert int(s.get_runtime()[2]) == o.finish_iter()
+    assert np.array_equal(tr["corr"][:n], tro["corr"][:n]), "per-iteration correspondence positions"
+    assert np.allclose(tr["H"][:n], tro["H"][:n], rtol=1e-11, atol=1e-9)
+    assert np.allclose(tr["b"][:n], tro["b"][:n], rtol=1e-9, atol=1e-9)
+    assert np.allclose(tr["newton"][:n], tro["newton"][:n], rtol=1e-7, atol=1e-10)
+    assert np.allclose(tr["phi"][:n], tro["phi"][:n], rtol=1e-7, atol=1e-10)
+    if P > 1:
+        assert np.allclose(tr["h"][:n], tro["h"][:n], rtol=1e-10)
+    assert np.abs(s.get_transformation() - o.get_transformation()).max() < strict_pose
+    assert np.allclose(s.get_distribution(), o.get_distribution(), atol=strict_pose)
+    assert np.allclose(s.get_cov_matrix(), o.get_cov_matrix(), atol=strict_pose)
+    assert np.allclose(s.get_particles(), o.get_particles(), atol=strict_pose)
+    assert np.array_equal(s.get_particle_weight(), o.get_particle_weight())
+    assert np.allclose(s.get_particle_history(), o.get_particle_history(), atol=1e-6)
+
+
+# ------------------------------------------------------------------ golden fixtures (SVN mode)
+@pytest.mark.parametrize("name", golden_cases("svn"))
+def test_hip_reproduces_golden(hip, orc, name):
+    g = load_golden(name)
+    s = _hip_solver(hip, g["init"], **g["cfg"])
+    s.add_cloud(g["src"], g["tgt"], g["init"])
+    s.set_initial_mean((g["R0"], g["t0"]))
+    assert s.stein_align() == int(g["state"])
+    n = int(g["iters_run"])
+    assert np.array_equal(s.get_candidates(), g["cand_idx"])
+    tr = s.get_trace()
+    assert (tr["corr"][:n] != g["corr"]).mean() <= 1e-4
+    assert np.allclose(tr["phi"][:n], g["phi"], atol=TIGHT)
+    assert np.allclose(tr["H"][:n], g["H"], rtol=1e-11, atol=1e-9)
+    assert np.abs(s.get_transformation()[:3] - g["mean"][:3]).max() < POSE_TOL  # the stated bar …
+    assert np.abs(s.get_transformation()[3:] - g["mean"][3:]).max() < POSE_TOL
+    assert np.allclose(s.get_transformation(), g["mean"], atol=TIGHT)            # … and the tight one
+    assert np.allclose(s.get_cov_matrix(), g["cov"], atol=TIGHT)
+    assert np.allclose(s.get_distribution(), g["var"], atol=TIGHT)
+    assert np.allclose(s.get_particles(), g["particles"], atol=TIGHT)
+    assert np.array_equal(s.get_particle_weight(), g["weights"])
+    assert np.allclose(s.get_particle_history(), g["history"], atol=1e-6)
+    # and against the oracle run on the same inputs
+    o = oracle_from_golden(orc, g)
+    tro = o.enable_trace(); o.stein_align()
+    _compare(s, o, tro, g["init"].shape[1])
+
+
+# ------------------------------------------------------------------ seeded cases vs the oracle
+CASES = [
+    # P, B, M, K, I, full, early_stop, thr, max_dist, lr
+    (1, 256, 1000, 7, 8, False, False, 1e-5, 1.0, 1.0),      # plain ICP, one particle
+    (1, 1, 50, 1, 3, False, False, 1e-5, 1.0, 1.0),          # single source point, K = 1
+    (3, 65, 130, 1, 4, True, False, 1e-5, 1.0, 1.0),         # ragged sizes, K = 1
+    (4, 300, 1000, 10, 8, True, False, 1e-5, 1.0, 0.5),
+    (8, 512, 2048, 32, 10, False, False, 1e-5, 0.05, 1.0),   # many rows masked by point_filter
+    (8, 512, 2048, 32, 1, False, False, 1e-5, 1e-9, 1.0),    # every row masked: H = B·I₃ ⊕ 1e-6 (degenerate: 1 iteration)
+    (8, 512, 2048, 32, 30, True, True, 2e-2, 1.0, 1.0),      # early stop fires
+    (33, 200, 150, 100, 5, False, False, 1e-5, 1.0, 1.0),    # K close to M
+    (5, 100, 40, 64, 3, False, False, 1e-5, 1.0, 1.0),       # M < K: padded candidates (idx 0)
+    (64, 256, 500, 16, 6, True, False, 1e-5, 1.0, 0.5),
+    (128, 2048, 8192, 100, 5, False, False, 1e-5, 1.0, 1.0), # two particle waves per workgroup
+    (130, 1000, 5000, 100, 4, True, False, 1e-5, 1.0, 1.0),  # particle count not a multiple of 64
+    (300, 700, 3000, 24, 3, False, False, 1e-5, 1.0, 1.0),   # two particle groups (grid.y = 2)
+    (32, 4096, 8192, 100, 6, False, False, 1e-5, 1.0, 1.0),
+    (16, 3000, 9000, 200, 4, False, False, 1e-5, 1.0, 1.0),  # K > 128: larger candidate pool
+]
+
+
+@pytest.mark.parametrize("P,B,M,K,I,full,es,thr,md,lr", CASES)
+def test_hip_vs_oracle(hip, orc, P, B, M, K, I, full, es, thr, md, lr):
+    src, tgt = hip.scans.random_clouds(B, M, seed=P + B)
+    init = hip.scans.make_particles(P, seed=P) * 0.3
+    R0, t0 = hip.scans.rot_zyx(0.001, 0.002, -0.001), np.array([0.01, -0.02, 0.005])
+    cfg = dict(iterations=I, lr=lr, max_dist=md, check_early_stop=es, convergence_threshold=thr, knn_count=K,
+               svn_full_grad=full)
+    o = orc.Solver(init, **cfg)
+    o.add_cloud(src, tgt, init); o.set_initial_mean(R0, t0)
+    tro = o.enable_trace(); o.stein_align()
+    s = _hip_solver(hip, init, **cfg)
+    s.add_cloud(src, tgt, init); s.set_initial_mean((R0, t0))
+    assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+    _compare(s, o, tro, P)
+
+
+def test_exact_ties_lowest_index_wins(hip, orc):
+    """Integer-grid clouds: distances are exact and massively tied in stage A and stage B; the HIP
+    path must break every tie like the reference CPU KNN (lowest index / first position)."""
+    rng = np.random.default_rng(0)
+    tgt = rng.integers(-5, 6, size=(3000, 3)).astype(np.float64)
+    src = rng.integers(-5, 6, size=(500, 3)).astype(np.float64)
+    init = np.zeros((6, 4)); init[0] = [0.0, 1.0, -2.0, 0.5]   # exact translations: stage-B ties stay exact
+    cfg = dict(iterations=1, lr=1.0, max_dist=100.0, knn_count=40, svn_full_grad=False)
+    o = orc.Solver(init, **cfg); o.add_cloud(src, tgt, init); tro = o.enable_trace(); o.stein_align()
+    s = _hip_solver(hip, init, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+    ci = s.get_candidates().astype(np.int64)
+    assert np.array_equal(ci, o.candidates())
+    d2 = s.get_candidate_dist2()
+    tied = np.diff(d2, axis=1) == 0
+    assert tied.mean() > 0.3 and np.all(np.diff(ci, axis=1)[tied] > 0)
+    assert np.array_equal(s.get_trace()["corr"][:1], tro["corr"][:1])
+
+
+def test_device_pointer_inputs_and_determinism(hip):
+    import torch
+    src, tgt = hip.scans.random_clouds(3000, 9000, seed=11)
+    init = hip.scans.make_particles(40, seed=11) * 0.3
+    cfg = dict(iterations=6, lr=1.0, max_dist=1.0, knn_count=50, svn_full_grad=True)
+    a = _hip_solver(hip, init, trace=False, **cfg); a.add_cloud(src, tgt, init); a.stein_align()
+    b = _hip_solver(hip, init, trace=False, **cfg)
+    b.add_cloud(torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), init); b.stein_align()
+    assert np.array_equal(a.get_particles(), b.get_particles())      # host vs device inputs: same bits
+    a.add_cloud(src, tgt, init); a.stein_align()                      # context re-use, run-to-run determinism
+    assert np.array_equal(a.get_particles(), b.get_particles())
+    assert np.array_equal(a.get_cov_matrix(), b.get_cov_matrix())
+
+
+def test_context_reuse_with_changing_sizes(hip, orc):
+    init = hip.scans.make_particles(12, seed=2) * 0.3
+    cfg = dict(iterations=4, lr=1.0, max_dist=1.0, knn_count=20, svn_full_grad=False)
+    s = _hip_solver(hip, init, trace=False, **cfg)
+    for (B, M, K, md) in [(500, 2000, 20, 1.0), (1500, 700, 9, 0.5), (64, 64, 64, 1.0)]:
+        src, tgt = hip.scans.random_clouds(B, M, seed=B)
+        s.set_k(K); s.set_threshold(md)
+        s.add_cloud(src, tgt, init); s.set_initial_mean(np.eye(4)); s.stein_align()
+        o = orc.Solver(init, **dict(cfg, knn_count=K, max_dist=md)); o.add_cloud(src, tgt, init); o.stein_align()
+        assert np.array_equal(s.get_candidates().astype(np.int64), o.candidates())
+        assert np.abs(s.get_transformation() - o.get_transformation()).max() < TIGHT
+
+
+def test_error_paths(hip):
+    s = hip.SVNICP(hip.SteinICPParam(iterations=2, KNN_count=4), np.zeros((6, 2)))
+    with pytest.raises(hip.SvnIcpError):
+        s.stein_align()                       # no clouds yet
+    with pytest.raises(hip.SvnIcpError):
+        s.get_transformation()                # no result yet
+    with pytest.raises(hip.SvnIcpError):
+        hip.SVNICP(hip.SteinICPParam(iterations=2, KNN_count=0), np.zeros((6, 2)))
+
+
+# ------------------------------------------------------------------ split-phase ABI (multi-GPU path) on one GPU
+def test_split_phase_two_shards_equal_single_context(hip):
+    """Two contexts on one GPU play two ranks: particle shards [0,P/2) and [P/2,P), candidate rows
+    split in two; the 'all-gathers' are host copies.  Result must equal the one-shot svnicp_align."""
+    import torch
+    L = hip.load_library()
+    P, B, M, K, I = 24, 1200, 4000, 30, 5
+    src, tgt = hip.scans.random_clouds(B, M, seed=5)
+    init = hip.scans.make_particles(P, seed=5) * 0.3
+    cfg = dict(iterations=I, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=True)
+    ref = _hip_solver(hip, init, trace=False, **cfg); ref.add_cloud(src, tgt, init); ref.stein_align()
+    ranks = []
+    for r in range(2):
+        s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init)
+        assert L.svnicp_set_shard(s.handle, r * P // 2, (r + 1) * P // 2) == 0
+        assert L.svnicp_align_begin(s.handle) == 0
+        assert L.svnicp_stage_candidates(s.handle, r * B // 2, (r + 1) * B // 2) == 0
+        ranks.append(s)
+
+    def view(s, fn, shape, dt):
+        from svnicp_amd.sharded import _DevView
+        return torch.as_tensor(_DevView(getattr(L, fn)(s.handle), shape, dt), device="cuda")
+    for s in ranks:
+        L.svnicp_synchronize(s.handle)
+    c0, c1 = (view(s, "svnicp_candidates_devptr", (B, K), "<i4") for s in ranks)
+    c0[B // 2:] = c1[B // 2:]; c1[:B // 2] = c0[:B // 2]
+    torch.cuda.synchronize()
+    for s in ranks:
+        assert L.svnicp_build_candidate_table(s.handle) == 0
+    for it in range(I):
+        for s in ranks:
+            assert L.svnicp_iter_accumulate(s.handle, it) == 0
+            L.svnicp_synchronize(s.handle)
+        r0, r1 = (view(s, "svnicp_sums_devptr", (P, 22), "<f8") for s in ranks)
+        r0[P // 2:] = r1[P // 2:]; r1[:P // 2] = r0[:P // 2]
+        torch.cuda.synchronize()
+        for s in ranks:
+            assert L.svnicp_iter_update(s.handle, it) == 0
+    for s in ranks:
+        assert L.svnicp_finish(s.handle) == 0
+        L.svnicp_synchronize(s.handle)
+        # a shard of P/2 particles uses a different lane tiling (hence summation order) than the
+        # one-shot run: equal to rounding, not bitwise …
+        assert np.allclose(s.get_particles(), ref.get_particles(), rtol=0, atol=1e-12)
+        assert np.allclose(s.get_cov_matrix(), ref.get_cov_matrix(), rtol=0, atol=1e-12)
+        assert np.array_equal(s.get_candidates(), ref.get_candidates())
+    # … but the two replicas must agree bit for bit (identical inputs, identical code)
+    assert np.array_equal(ranks[0].get_particles(), ranks[1].get_particles())
+    assert np.array_equal(ranks[0].get_cov_matrix(), ranks[1].get_cov_matrix())
+
+
+def test_sharded_driver_world1_equals_plain(hip):
+    from svnicp_amd.sharded import ShardedSVNICP
+    P, B, M = 10, 800, 2500
+    src, tgt = hip.scans.random_clouds(B, M, seed=9)
+    init = hip.scans.make_particles(P, seed=9) * 0.3
+    prm = hip.SteinICPParam(iterations=4, lr=1.0, max_dist=1.0, KNN_count=16, SVN_full_grad=False)
+    a = hip.SVNICP(prm, init); a.add_cloud(src, tgt, init); a.stein_align()
+    b = ShardedSVNICP(prm, init, device_index=0); b.add_cloud(src, tgt, init); b.set_initial_mean(np.eye(4))
+    b.stein_align()
+    assert np.array_equal(a.get_particles(), b.get_particles())
+
+
+# ------------------------------------------------------------------ BASELINE sizes
+def test_c1_full_parity(hip, orc):
+    """BASELINE config C1 (the reference-CPU-path config): 1 particle, 4096 x 8192, 20 iterations."""
+    cfg = hip.scans.CONFIGS["C1"]
+    pair = hip.scans.make_pair(cfg["B"], cfg["M"]); init = hip.scans.make_particles(1)
+    c = dict(iterations=20, lr=1.0, max_dist=1.0, knn_count=100, svn_full_grad=False)
+    o = orc.Solver(init, **c); o.add_cloud(pair.source, pair.target, init); tro = o.enable_trace(); o.stein_align()
+    s = _hip_solver(hip, init, **c); s.add_cloud(pair.source, pair.target, init); s.stein_align()
+    _compare(s, o, tro, 1)
+
+
+def test_c2_full_parity(hip, orc):
+    """BASELINE config C2 at full size against the oracle (all host cores): indices bit-exact,
+    pose within the stated 1e-4 bar (and in fact ~1e-12)."""
+    cfg = hip.scans.CONFIGS["C2"]
+    pair = hip.scans.make_pair(cfg["B"], cfg["M"]); init = hip.scans.make_particles(cfg["P"])
+    c = dict(iterations=5, lr=1.0, max_dist=1.0, knn_count=100, svn_full_grad=False)   # 5 of the 20 iterations: CPU time
+    o = orc.Solver(init, **c); o.add_cloud(pair.source, pair.target, init); o.stein_align()
+    s = _hip_solver(hip, init, trace=False, **c); s.add_cloud(pair.source, pair.target, init); s.stein_align()
+    assert np.array_equal(s.get_candidates().astype(np.int64), o.candidates())
+    assert np.array_equal(s.get_candidate_dist2(), o.candidate_dist2())
+    err = np.abs(s.get_transformation() - o.get_transformation())
+    assert err[:3].max() < POSE_TOL and err[3:].max() < POSE_TOL
+    assert err.max() < 1e-9
+    assert np.allclose(s.get_cov_matrix(), o.get_cov_matrix(), atol=1e-9)
+
+
+def test_c3_headline_properties(hip, orc):
+    """Headline config C3 at full size through size-independent properties: (a) a random sample of
+    candidate rows equals the oracle's brute force on those rows bit-for-bit, (b) every row is
+    ascending by (dist², idx) with in-range indices, (c) the run is deterministic, (d) weights sum
+    to one and the covariance is symmetric PSD, (e) the registration moves toward the planted pose."""
+    cfg = hip.scans.CONFIGS["C3"]
+    pair = hip.scans.make_pair(cfg["B"], cfg["M"]); init = hip.scans.make_particles(cfg["P"])
+    c = dict(iterations=20, lr=1.0, max_dist=1.0, knn_count=100, svn_full_grad=False)
+    s = _hip_solver(hip, init, trace=False, **c); s.add_cloud(pair.source, pair.target, init); s.stein_align()
+    ci, d2 = s.get_candidates(), s.get_candidate_dist2()
+    rows = np.random.default_rng(1).choice(cfg["B"], 256, replace=False)
+    oi, od = orc.knn_topk(pair.source[rows], pair.target, 100)
+    assert np.array_equal(ci[rows].astype(np.int64), oi) and np.array_equal(d2[rows], od)
+    assert ci.min() >= 0 and ci.max() < cfg["M"]
+    dd = np.diff(d2, axis=1)
+    assert np.all(dd >= 0) and np.all(np.diff(ci, axis=1)[dd == 0] > 0)
+    p1, cov = s.get_particles(), s.get_cov_matrix().reshape(6, 6)
+    s.add_cloud(pair.source, pair.target, init); s.stein_align()
+    assert np.array_equal(p1, s.get_particles())
+    assert abs(s.get_particle_weight().sum() - 1.0) < 1e-6
+    assert np.allclose(cov, cov.T, atol=1e-15) and np.linalg.eigvalsh(cov).min() > -1e-12
+    m = s.get_transformation()
+    assert np.linalg.norm(m[:3] - pair.true_pose[:3]) < np.linalg.norm(pair.true_pose[:3])
+    assert np.isfinite(s.get_particle_history()).all()

@@ -76,6 +76,15 @@ def lib():
         L.orc_get_candidates.restype = ip64
         L.orc_get_candidate_dist2.argtypes = [C.c_void_p]
         L.orc_get_candidate_dist2.restype = dp
+        L.orc_sp_begin.argtypes = [C.c_void_p]
+        L.orc_sp_candidate_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L.orc_sp_candidates.argtypes = [C.c_void_p]
+        L.orc_sp_candidates.restype = ip64
+        L.orc_sp_build_table.argtypes = [C.c_void_p]
+        L.orc_sp_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]
+        L.orc_sp_update.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_sp_update.restype = C.c_int
+        L.orc_sp_finish.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 

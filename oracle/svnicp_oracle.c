@@ -355,24 +355,37 @@ void orc_set_trace(orc_solver *s, const orc_trace *t) {
 }
 
 /* SVGDICP.cpp:176-215  mini_batch_pair_generator + knn_source_cloud (use_minibatch is never
- * set => batch == whole source, the same candidates every epoch) */
-static void candidate_stage(orc_solver *s) {
-  const int64_t B = s->B, M = s->M;
+ * set => batch == whole source, the same candidates every epoch).  Split in "rows" + "table" so
+ * that the test-side sharded backend can compute a row range per rank. */
+static void candidate_alloc(orc_solver *s) {
+  const int64_t B = s->B;
   const int K = s->K;
   free(s->cand_idx); free(s->cand_d2); free(s->cand_xyz);
-  s->cand_idx = (int64_t *)malloc((size_t)B * K * 8);
-  s->cand_d2 = (double *)malloc((size_t)B * K * 8);
+  s->cand_idx = (int64_t *)calloc((size_t)B * K, 8);
+  s->cand_d2 = (double *)calloc((size_t)B * K, 8);
   s->cand_xyz = (double *)malloc((size_t)B * K * 24);
-  double *q = (double *)malloc((size_t)B * 24);
-  orc_transform(s->src, B, s->R0, s->t0, q);                         /* :204 */
-  orc_knn_topk(q, B, s->tgt, M, K, s->cand_idx, s->cand_d2);         /* :205-214 */
+}
+static void candidate_rows(orc_solver *s, int64_t b_lo, int64_t b_hi) {
+  const int K = s->K;
+  if (b_hi <= b_lo) return;
+  double *q = (double *)malloc((size_t)(b_hi - b_lo) * 24);
+  orc_transform(s->src + 3 * b_lo, b_hi - b_lo, s->R0, s->t0, q);                           /* :204 */
+  orc_knn_topk(q, b_hi - b_lo, s->tgt, s->M, K, s->cand_idx + b_lo * K, s->cand_d2 + b_lo * K); /* :205-214 */
   free(q);
-  for (int64_t e = 0; e < B * K; ++e) {                              /* :191-193 index_select */
+}
+static void candidate_table(orc_solver *s) {
+  const int64_t n = s->B * (int64_t)s->K;
+  for (int64_t e = 0; e < n; ++e) {                                  /* :191-193 index_select */
     const int64_t i = s->cand_idx[e];
     s->cand_xyz[3 * e + 0] = s->tgt[3 * i + 0];
     s->cand_xyz[3 * e + 1] = s->tgt[3 * i + 1];
     s->cand_xyz[3 * e + 2] = s->tgt[3 * i + 2];
   }
+}
+static void candidate_stage(orc_solver *s) {
+  candidate_alloc(s);
+  candidate_rows(s, 0, s->B);
+  candidate_table(s);
 }
 
 /* one (particle, source point): transform (SVNICP.cpp:62-64), nearest-of-K
@@ -401,15 +414,15 @@ static inline int correspond(const orc_solver *s, const double Rt[9], const doub
 
 #define CHUNK 2048 /* fixed chunking => results independent of the thread count */
 
-/* SVNICP.cpp:116-164 Newton_grad_right for all particles: H [P][36], b [P][6] */
-static void newton_accumulate(orc_solver *s, int epoch, double *H, double *bv) {
+/* SVNICP.cpp:116-164 Newton_grad_right for particles [p_lo,p_hi): H [P][36], b [P][6] */
+static void newton_accumulate_range(orc_solver *s, int epoch, int p_lo, int p_hi, double *H, double *bv) {
   const int P = s->P;
   const int64_t B = s->B;
   const int64_t nchunk = (B + CHUNK - 1) / CHUNK;
   const double md = s->prm.max_dist;
   double *part = (double *)calloc((size_t)P * nchunk * 42, 8);
 #pragma omp parallel for collapse(2) schedule(dynamic, 1) num_threads(NTHREADS())
-  for (int p = 0; p < P; ++p)
+  for (int p = p_lo; p < p_hi; ++p)
     for (int64_t ch = 0; ch < nchunk; ++ch) {
       double Rt[9], tt[3], tmp[3];
       mat3_mul(s->R0, s->R + 9 * p, Rt);            /* SVNICP.cpp:58,145 */
@@ -443,7 +456,7 @@ static void newton_accumulate(orc_solver *s, int epoch, double *H, double *bv) {
         }
       }
     }
-  for (int p = 0; p < P; ++p) {
+  for (int p = p_lo; p < p_hi; ++p) {
     double *Hp = H + 36 * p, *bp = bv + 6 * p;
     for (int i = 0; i < 36; ++i) Hp[i] = 0;
     for (int i = 0; i < 6; ++i) bp[i] = 0;
@@ -455,6 +468,10 @@ static void newton_accumulate(orc_solver *s, int epoch, double *H, double *bv) {
     for (int i = 0; i < 6; ++i) Hp[7 * i] += 1e-6;                           /* :153 */
   }
   free(part);
+}
+
+static void newton_accumulate(orc_solver *s, int epoch, double *H, double *bv) {
+  newton_accumulate_range(s, epoch, 0, s->P, H, bv);
 }
 
 static int cmp_double(const void *a, const void *b) {
@@ -563,61 +580,107 @@ static void alloc_history(orc_solver *s) { /* SVGDICP.cpp:172-174 */
   s->history = (float *)calloc((size_t)s->hist_I * 6 * s->P + 1, sizeof(float));
 }
 
+/* everything of one epoch after Newton_grad_right's sums: solve, Stein direction, pose update,
+ * early stop, history (SVNICP.cpp:71-107).  Returns 1 when the early stop fired. */
+static int svn_update(orc_solver *s, int epoch, double *H, double *bv) {
+  const int P = s->P;
+  double *N = (double *)malloc((size_t)P * 6 * 8), *phi = (double *)malloc((size_t)P * 6 * 8);
+  double *x = (double *)malloc((size_t)P * 6 * 8), *neg = (double *)malloc((size_t)P * 6 * 8);
+  int stop = 0;
+  for (int p = 0; p < P; ++p) orc_solve6(H + 36 * p, bv + 6 * p, N + 6 * p); /* :162 */
+  refresh_pose_svn(s);                                                        /* :74-77 */
+  for (int p = 0; p < P; ++p) for (int d = 0; d < 6; ++d) x[6 * p + d] = s->pose[d * P + p];
+  double h = NAN;
+  if (P > 1) {
+    if (s->prm.svn_full_grad) {
+      for (int i = 0; i < 6 * P; ++i) neg[i] = -bv[i];
+      svn_full_grad(x, H, neg, P, s->prm.lr, phi, &h);                        /* :83 */
+    } else {
+      double Hm[36] = {0};
+      for (int p = 0; p < P; ++p) for (int e = 0; e < 36; ++e) Hm[e] += H[36 * p + e];
+      for (int e = 0; e < 36; ++e) Hm[e] /= P;                                /* :85 */
+      for (int i = 0; i < 6 * P; ++i) neg[i] = -N[i];
+      svn_svgd_grad(x, neg, Hm, P, phi, &h);                                  /* :86 */
+    }
+  } else {
+    for (int i = 0; i < 6; ++i) phi[i] = -N[i];                               /* :89 */
+  }
+  if (s->has_trace) {
+    if (s->tr.H) memcpy(s->tr.H + (size_t)epoch * P * 36, H, (size_t)P * 36 * 8);
+    if (s->tr.b) memcpy(s->tr.b + (size_t)epoch * P * 6, bv, (size_t)P * 6 * 8);
+    if (s->tr.newton) memcpy(s->tr.newton + (size_t)epoch * P * 6, N, (size_t)P * 6 * 8);
+    if (s->tr.phi) memcpy(s->tr.phi + (size_t)epoch * P * 6, phi, (size_t)P * 6 * 8);
+    if (s->tr.h) s->tr.h[epoch] = h;
+  }
+  svn_pose_update(s, phi);                                                    /* :92 */
+  if (s->prm.check_early_stop) {                                              /* :95-101 */
+    double m = 0;
+    for (int p = 0; p < P; ++p) {
+      double n2 = 0;
+      for (int d = 0; d < 6; ++d) n2 += phi[6 * p + d] * phi[6 * p + d];
+      m += sqrt(n2);
+    }
+    m /= P;
+    /* torch::lt(f64 0-dim, f32 1-dim) computes in float32 (type promotion) */
+    if ((float)m < (float)s->prm.convergence_threshold) { s->finish_iter = epoch + 1; stop = 1; }
+  }
+  if (!stop) {
+    refresh_pose_svn(s);                                                      /* :103-106 */
+    for (int i = 0; i < 6 * P; ++i) s->history[(size_t)epoch * 6 * P + i] = (float)s->pose[i]; /* :107 */
+    if (s->has_trace && s->tr.pose) memcpy(s->tr.pose + (size_t)epoch * 6 * P, s->pose, (size_t)6 * P * 8);
+  }
+  free(N); free(phi); free(x); free(neg);
+  return stop;
+}
+
 static int svn_align(orc_solver *s) { /* SVNICP.cpp:41-114 */
   const int P = s->P, I = s->prm.iterations;
   alloc_history(s);
   candidate_stage(s);
   double *H = (double *)malloc((size_t)P * 36 * 8), *bv = (double *)malloc((size_t)P * 6 * 8);
-  double *N = (double *)malloc((size_t)P * 6 * 8), *phi = (double *)malloc((size_t)P * 6 * 8);
-  double *x = (double *)malloc((size_t)P * 6 * 8), *neg = (double *)malloc((size_t)P * 6 * 8);
   s->finish_iter = I;
   for (int epoch = 0; epoch < I; ++epoch) {
     newton_accumulate(s, epoch, H, bv);
-    for (int p = 0; p < P; ++p) orc_solve6(H + 36 * p, bv + 6 * p, N + 6 * p); /* :162 */
-    refresh_pose_svn(s);                                                        /* :74-77 */
-    for (int p = 0; p < P; ++p) for (int d = 0; d < 6; ++d) x[6 * p + d] = s->pose[d * P + p];
-    double h = NAN;
-    if (P > 1) {
-      if (s->prm.svn_full_grad) {
-        for (int i = 0; i < 6 * P; ++i) neg[i] = -bv[i];
-        svn_full_grad(x, H, neg, P, s->prm.lr, phi, &h);                        /* :83 */
-      } else {
-        double Hm[36] = {0};
-        for (int p = 0; p < P; ++p) for (int e = 0; e < 36; ++e) Hm[e] += H[36 * p + e];
-        for (int e = 0; e < 36; ++e) Hm[e] /= P;                                /* :85 */
-        for (int i = 0; i < 6 * P; ++i) neg[i] = -N[i];
-        svn_svgd_grad(x, neg, Hm, P, phi, &h);                                  /* :86 */
-      }
-    } else {
-      for (int i = 0; i < 6; ++i) phi[i] = -N[i];                               /* :89 */
-    }
-    if (s->has_trace) {
-      if (s->tr.H) memcpy(s->tr.H + (size_t)epoch * P * 36, H, (size_t)P * 36 * 8);
-      if (s->tr.b) memcpy(s->tr.b + (size_t)epoch * P * 6, bv, (size_t)P * 6 * 8);
-      if (s->tr.newton) memcpy(s->tr.newton + (size_t)epoch * P * 6, N, (size_t)P * 6 * 8);
-      if (s->tr.phi) memcpy(s->tr.phi + (size_t)epoch * P * 6, phi, (size_t)P * 6 * 8);
-      if (s->tr.h) s->tr.h[epoch] = h;
-    }
-    svn_pose_update(s, phi);                                                    /* :92 */
-    if (s->prm.check_early_stop) {                                              /* :95-101 */
-      double m = 0;
-      for (int p = 0; p < P; ++p) {
-        double n2 = 0;
-        for (int d = 0; d < 6; ++d) n2 += phi[6 * p + d] * phi[6 * p + d];
-        m += sqrt(n2);
-      }
-      m /= P;
-      /* torch::lt(f64 0-dim, f32 1-dim) computes in float32 (type promotion) */
-      if ((float)m < (float)s->prm.convergence_threshold) { s->finish_iter = epoch + 1; break; }
-    }
-    refresh_pose_svn(s);                                                        /* :103-106 */
-    for (int i = 0; i < 6 * P; ++i) s->history[(size_t)epoch * 6 * P + i] = (float)s->pose[i]; /* :107 */
-    if (s->has_trace && s->tr.pose) memcpy(s->tr.pose + (size_t)epoch * 6 * P, s->pose, (size_t)6 * P * 8);
+    if (svn_update(s, epoch, H, bv)) break;
   }
-  refresh_pose_svn(s);                                                          /* :111-112 */
-  free(H); free(bv); free(N); free(phi); free(x); free(neg);
+  refresh_pose_svn(s);                                                        /* :111-112 */
+  free(H); free(bv);
   return ORC_ALIGN_SUCCESS;
 }
+
+/* ---- split-phase form (SVN mode) used only by the CPU test of the sharded driver
+ * (tests/oracle_backend.py): same arithmetic as svn_align, cut at the two exchange points. ---- */
+void orc_sp_begin(orc_solver *s) {
+  alloc_history(s);
+  candidate_alloc(s);
+  s->finish_iter = s->prm.iterations;
+}
+void orc_sp_candidate_rows(orc_solver *s, int64_t b_lo, int64_t b_hi) { candidate_rows(s, b_lo, b_hi); }
+int64_t *orc_sp_candidates(orc_solver *s) { return s->cand_idx; }
+void orc_sp_build_table(orc_solver *s) { candidate_table(s); }
+/* rec: [P][42] = H (36) | b (6); only rows [p_lo,p_hi) are written */
+void orc_sp_accumulate(orc_solver *s, int epoch, int p_lo, int p_hi, double *rec) {
+  const int P = s->P;
+  double *H = (double *)malloc((size_t)P * 36 * 8), *bv = (double *)malloc((size_t)P * 6 * 8);
+  newton_accumulate_range(s, epoch, p_lo, p_hi, H, bv);
+  for (int p = p_lo; p < p_hi; ++p) {
+    memcpy(rec + (size_t)p * 42, H + 36 * p, 36 * 8);
+    memcpy(rec + (size_t)p * 42 + 36, bv + 6 * p, 6 * 8);
+  }
+  free(H); free(bv);
+}
+int orc_sp_update(orc_solver *s, int epoch, const double *rec) {
+  const int P = s->P;
+  double *H = (double *)malloc((size_t)P * 36 * 8), *bv = (double *)malloc((size_t)P * 6 * 8);
+  for (int p = 0; p < P; ++p) {
+    memcpy(H + 36 * p, rec + (size_t)p * 42, 36 * 8);
+    memcpy(bv + 6 * p, rec + (size_t)p * 42 + 36, 6 * 8);
+  }
+  const int stop = svn_update(s, epoch, H, bv);
+  free(H); free(bv);
+  return stop;
+}
+void orc_sp_finish(orc_solver *s) { refresh_pose_svn(s); }
 
 /* ------------------------------- SVGD mode ------------------------------------------------ */
 

@@ -100,6 +100,15 @@ int orc_get_finish_iter(orc_solver *s);
 const int64_t *orc_get_candidates(orc_solver *s);
 const double *orc_get_candidate_dist2(orc_solver *s);
 
+/* split-phase form of the SVN path, for the CPU (gloo) test of the sharded driver only */
+void orc_sp_begin(orc_solver *s);
+void orc_sp_candidate_rows(orc_solver *s, int64_t b_lo, int64_t b_hi);
+int64_t *orc_sp_candidates(orc_solver *s);
+void orc_sp_build_table(orc_solver *s);
+void orc_sp_accumulate(orc_solver *s, int epoch, int p_lo, int p_hi, double *recPx42);
+int orc_sp_update(orc_solver *s, int epoch, const double *recPx42);
+void orc_sp_finish(orc_solver *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,7 +55,12 @@ struct svnicp_ctx {
 
   DevBuf<double> src, tgt, tx, ty, tz, pool_d, cand_d2, table, init_pose, R, t, Rtot, pose_out, sums, partial, work,
       stats, trH, trb, trN, trphi, trh;
-  DevBuf<int32_t> pool_i, cand_idx, trcorr, torig;
+  DevBuf<int32_t> pool_i, cand_idx, trcorr, torig, pool2, fail_list;
+  DevBuf<float> txf, tyf, tzf;
+  DevBuf<unsigned long long> emax;
+  DevBuf<int> fail_count;
+  bool use_scan = false;   // stage A through knn_scan.hip (f32 pre-filter) with knn_topk.hip as fallback
+  int64_t scan_Ms = 0; int scan_rank = 0, scan_S2 = 0;
   DevBuf<float> history;
   DevBuf<int> ctl;
   int hist_I = 0, hist_P = 0;
@@ -67,6 +72,8 @@ struct svnicp_ctx {
   std::vector<int> pcls;                // kernel class of pair i
   size_t pused = 0;
 };
+
+constexpr int kFallbackGrid = 16;  // workgroups of the streaming kernel when it only redoes failed queries
 
 enum { KC_KNN = 0, KC_TABLE = 1, KC_ACCUM = 2, KC_REDUCE = 3, KC_UPDATE = 4, KC_COUNT = 5 };
 
@@ -169,7 +176,7 @@ void svnicp_destroy(svnicp_ctx* c) {
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
   for (auto* b : dbl) b->release();
-  c->pool_i.release(); c->torig.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->pev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -204,7 +211,12 @@ int svnicp_set_clouds(svnicp_ctx* c, const double* src, int64_t B, const double*
   HIPCHK(c, c->ty.ensure((size_t)c->Mp));
   HIPCHK(c, c->tz.ensure((size_t)c->Mp));
   HIPCHK(c, c->torig.ensure((size_t)c->Mp));
-  HIPCHK(c, launch_targets_soa(c->tgt.p, M, c->Mp, c->tx.p, c->ty.p, c->tz.p, c->torig.p, c->stream));
+  HIPCHK(c, c->txf.ensure((size_t)c->Mp));
+  HIPCHK(c, c->tyf.ensure((size_t)c->Mp));
+  HIPCHK(c, c->tzf.ensure((size_t)c->Mp));
+  HIPCHK(c, c->emax.ensure(1));
+  HIPCHK(c, launch_targets_soa2(c->tgt.p, M, c->Mp, c->tx.p, c->ty.p, c->tz.p, c->txf.p, c->tyf.p,
+                                c->tzf.p, c->torig.p, c->emax.p, c->stream));
   if (mem_kind != SVNICP_MEM_DEVICE) HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse its host buffers
   c->clouds_set = true;
   c->have_candidates = false;
@@ -278,8 +290,20 @@ int svnicp_align_begin(svnicp_ctx* c) {
   const int I = c->prm.iterations, P = c->P;
   const int64_t B = c->B;
   c->S = knn_pool_size(c->K);
-  HIPCHK(c, c->pool_d.ensure((size_t)B * c->S));
-  HIPCHK(c, c->pool_i.ensure((size_t)B * c->S));
+  {
+    const char* force_v1 = getenv("SVNICP_KNN_V1");  // A/B switch for tests and profiling
+    c->use_scan = !(force_v1 && force_v1[0] == '1') && knn_scan_plan(c->Mp, c->K, &c->scan_Ms, &c->scan_rank, &c->scan_S2);
+  }
+  if (c->use_scan) {
+    HIPCHK(c, c->pool2.ensure((size_t)B * c->scan_S2));
+    HIPCHK(c, c->fail_list.ensure((size_t)B));
+    HIPCHK(c, c->fail_count.ensure(1));
+    HIPCHK(c, c->pool_d.ensure((size_t)kFallbackGrid * 256 * c->S));   // fallback rows only
+    HIPCHK(c, c->pool_i.ensure((size_t)kFallbackGrid * 256 * c->S));
+  } else {
+    HIPCHK(c, c->pool_d.ensure((size_t)B * c->S));
+    HIPCHK(c, c->pool_i.ensure((size_t)B * c->S));
+  }
   HIPCHK(c, c->cand_idx.ensure((size_t)B * c->K));
   HIPCHK(c, c->cand_d2.ensure((size_t)B * c->K));
   HIPCHK(c, c->table.ensure((size_t)B * c->K * 3));
@@ -328,9 +352,22 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
   a.src = c->src.p; a.pose = c->pose0; a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p; a.torig = c->torig.p;
   a.M = c->M; a.Mp = c->Mp; a.b_lo = b_lo; a.b_hi = b_hi; a.K = c->K; a.S = c->S;
   a.pool_d = c->pool_d.p; a.pool_i = c->pool_i.p; a.out_idx = c->cand_idx.p; a.out_d2 = c->cand_d2.p;
-  { const char* e = getenv("SVNICP_DBG"); a.dbg = e ? atoi(e) : 0; }
   HIPCHK(c, prof_begin(c, KC_KNN));
-  HIPCHK(c, launch_knn_topk(a, c->stream));
+  if (c->use_scan) {
+    KnnScanArgs k{};
+    k.src = c->src.p; k.pose = c->pose0; k.tx = c->tx.p; k.ty = c->ty.p; k.tz = c->tz.p;
+    k.txf = c->txf.p; k.tyf = c->tyf.p; k.tzf = c->tzf.p; k.torig = c->torig.p; k.emax_bits = c->emax.p;
+    k.M = c->M; k.Mp = c->Mp; k.Ms = c->scan_Ms; k.b_lo = b_lo; k.b_hi = b_hi; k.K = c->K; k.S2 = c->scan_S2;
+    k.seed_rank = c->scan_rank; k.pool = c->pool2.p; k.out_idx = c->cand_idx.p; k.out_d2 = c->cand_d2.p;
+    k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p;
+    HIPCHK(c, hipMemsetAsync(c->fail_count.p, 0, sizeof(int), c->stream));
+    HIPCHK(c, launch_knn_scan(k, c->stream));
+    // redo the (rare) queries whose seeded threshold was too tight: streaming kernel, list mode
+    a.qlist = c->fail_list.p; a.qlist_count = c->fail_count.p; a.list_grid = kFallbackGrid;
+    HIPCHK(c, launch_knn_topk(a, c->stream));
+  } else {
+    HIPCHK(c, launch_knn_topk(a, c->stream));
+  }
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;
 }
@@ -487,6 +524,13 @@ int svnicp_get_runtime(svnicp_ctx* c, double out3[3]) {
   if (rc) return rc;
   out3[0] = ms[0] * 1e-3; out3[1] = ms[1] * 1e-3; out3[2] = (double)v[1];
   return SVNICP_OK;
+}
+
+int svnicp_get_knn_fallbacks(svnicp_ctx* c, int* out) {
+  CTX_CHECK(c);
+  if (!c->have_candidates) return fail(c, SVNICP_ERR_INVALID, "no candidates yet");
+  if (!c->use_scan) { *out = -1; return SVNICP_OK; }
+  return fetch(c, out, c->fail_count.p, sizeof(int));
 }
 
 int svnicp_set_profile(svnicp_ctx* c, int on) {

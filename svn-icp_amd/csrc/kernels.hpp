@@ -17,12 +17,35 @@ struct KnnArgs {
   int32_t* pool_i;     // [B][S]
   int32_t* out_idx;    // [B][K]
   double* out_d2;      // [B][K]
-  int dbg;             // bring-up experiments only (SVNICP_DBG env): 1 = skip slow path, 2 = skip merges
+  const int32_t* qlist;     // list mode (fallback of k_knn_scan): query indices, else nullptr
+  const int* qlist_count;   // device scalar: number of entries of qlist
+  int list_grid;            // list mode: number of workgroups (pool rows = list_grid*256)
 };
 int knn_pool_size(int K);
 int64_t knn_padded_targets(int64_t M);
-hipError_t launch_targets_soa(const double* tgt, int64_t M, int64_t Mp, double* tx, double* ty, double* tz,
-                              int32_t* torig, hipStream_t st);
+
+// ---------------- Stage A fast variant (knn_scan.hip) ----------------
+struct KnnScanArgs {
+  const double* src;
+  Pose0 pose;
+  const double *tx, *ty, *tz;     // f64 permuted SoA (exact distances of the survivors)
+  const float *txf, *tyf, *tzf;   // f32 copies (pre-filter)
+  const int32_t* torig;
+  const unsigned long long* emax_bits;  // max |target coordinate| as the bits of a non-negative double
+  int64_t M, Mp, Ms;              // Ms = slots scanned in the seed phase
+  int64_t b_lo, b_hi;
+  int K, S2, seed_rank;
+  int32_t* pool;                  // [B][S2] slots
+  int32_t* out_idx;               // [B][K]
+  double* out_d2;                 // [B][K]
+  int32_t* fail_list;             // [B]
+  int* fail_count;
+};
+bool knn_scan_plan(int64_t Mp, int K, int64_t* Ms, int* seed_rank, int* S2);
+hipError_t launch_targets_soa2(const double* tgt, int64_t M, int64_t Mp, double* tx, double* ty, double* tz,
+                               float* txf, float* tyf, float* tzf, int32_t* torig, unsigned long long* emax_bits,
+                               hipStream_t st);
+hipError_t launch_knn_scan(const KnnScanArgs& a, hipStream_t st);
 hipError_t launch_knn_topk(const KnnArgs& a, hipStream_t st);
 hipError_t launch_build_table(const int32_t* idx, int64_t n_entries, const double* tgt, double* table,
                               hipStream_t st);

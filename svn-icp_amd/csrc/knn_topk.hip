@@ -12,9 +12,10 @@
 //    and its running threshold are wave-uniform (LDS broadcast reads).
 //  * the hot loop is 8 f64 VALU ops + 1 compare per pair, no data-dependent work: a pair only
 //    leaves the fast path when d² <= thr (≈ K·ln(M/K) times per query out of M).
-//  * the target stream is visited in a golden-ratio-stride permutation j → (j·A) mod Mp, so every
-//    256-point tile is a uniform sample of the cloud: scan-ordered input would otherwise tighten
-//    the threshold gradually and push ~100× more pairs through the slow path (measured).
+//  * the target stream is stored in a pseudo-random permutation (k_targets_soa2, knn_scan.hip), so
+//    every 256-slot tile is a uniform sample of the cloud:
+//    scan-ordered input would otherwise tighten the threshold gradually and push ~100× more pairs
+//    through the slow path (measured: 118 ms → 35 ms at C3).
 //  * survivors are compacted with ballot/mbcnt into the query's candidate pool (global, L2
 //    resident, touched rarely); when a pool is nearly full the wave bitonic-sorts it in LDS by
 //    (d², idx), keeps the best K and lowers the threshold.  The filter uses '<=' on a
@@ -88,119 +89,114 @@ __global__ __launch_bounds__(256) void k_knn_topk(KnnArgs a) {
   const int wave = threadIdx.x >> 6;
   const int S = a.S, K = a.K;
   // per-wave LDS carve-up
-  const size_t per_wave = sizeof(QSlot) * QW + sizeof(int) * QW + (size_t)S * (sizeof(double) + sizeof(int));
+  const size_t per_wave = sizeof(QSlot) * QW + 2 * sizeof(int) * QW + (size_t)S * (sizeof(double) + sizeof(int));
   unsigned char* base = smem + per_wave * wave;
   QSlot* qv = reinterpret_cast<QSlot*>(base);
   double* sd = reinterpret_cast<double*>(base + sizeof(QSlot) * QW);
   int* si = reinterpret_cast<int*>(base + sizeof(QSlot) * QW + sizeof(double) * (size_t)S);
   int* cnt = si + S;
+  int* qb = cnt + QW;  // global query index of each slot
 
-  const int64_t q0 = a.b_lo + ((int64_t)blockIdx.x * WAVES + wave) * QW;  // first query of this wave
-  if (q0 >= a.b_hi) return;  // whole wave idle (no block-level barriers are used in this kernel)
+  // direct mode: queries b_lo..b_hi, one 64-query chunk per wave.  list mode (fallback of
+  // knn_scan.hip): queries qlist[0..*qlist_count), chunks strided over the fixed grid.
+  const bool list_mode = a.qlist != nullptr;
+  const int64_t n_queries = list_mode ? (int64_t)*a.qlist_count : (a.b_hi - a.b_lo);
+  const int64_t n_chunks = (n_queries + QW - 1) / QW;
+  const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
+  const int64_t total_waves = (int64_t)gridDim.x * WAVES;
 
-  {  // load + transform this wave's queries: q = R0·s + t0 (SVGDICP.cpp:204)
-    const int64_t b = q0 + lane;
-    QSlot s;
-    if (b < a.b_hi) {
-      const double sx = a.src[3 * b], sy = a.src[3 * b + 1], sz = a.src[3 * b + 2];
-      const double* R = a.pose.R0;
-      s.x = (sx * R[0] + sy * R[1] + sz * R[2]) + a.pose.t0[0];
-      s.y = (sx * R[3] + sy * R[4] + sz * R[5]) + a.pose.t0[1];
-      s.z = (sx * R[6] + sy * R[7] + sz * R[8]) + a.pose.t0[2];
-      s.thr = __builtin_huge_val();
-    } else {
-      s.x = s.y = s.z = 0.0;
-      s.thr = -1.0;  // nothing passes d2 <= -1
-    }
-    qv[lane] = s;
-    cnt[lane] = 0;
-  }
-  wave_sync();
-  const int nq = (a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW;
-
-  double x[T], y[T], z[T], nx[T], ny[T], nz[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    x[t] = a.tx[t * kWave + lane]; y[t] = a.ty[t * kWave + lane]; z[t] = a.tz[t * kWave + lane];
-  }
-  for (int64_t tile = 0; tile < a.Mp; tile += STEP) {
-    const int64_t nt = (tile + STEP < a.Mp) ? tile + STEP : tile;  // prefetch next tile (or re-read last)
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      nx[t] = a.tx[nt + t * kWave + lane]; ny[t] = a.ty[nt + t * kWave + lane]; nz[t] = a.tz[nt + t * kWave + lane];
-    }
-    for (int q = 0; q < nq; ++q) {
-      const double2 q01 = *reinterpret_cast<const double2*>(&qv[q].x);
-      const double2 q23 = *reinterpret_cast<const double2*>(&qv[q].z);
-      const double qx = q01.x, qy = q01.y, qz = q23.x, thr = q23.y;
-      double d[T];
-      unsigned long long m[T];
-      unsigned long long any = 0;
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const double dx = qx - x[t], dy = qy - y[t], dz = qz - z[t];
-        d[t] = (dx * dx + dy * dy) + dz * dz;   // knn_cpu.cpp:43-50 order, unfused
-        m[t] = __ballot(d[t] <= thr);
-        any |= m[t];
+  for (int64_t chunk = wave_global; chunk < n_chunks; chunk += total_waves) {  // no block-level barriers inside
+    const int64_t c0 = chunk * QW;
+    const int nq = (n_queries - c0) < QW ? (int)(n_queries - c0) : QW;
+    const int64_t pool_row0 = list_mode ? wave_global * QW : a.b_lo + c0;
+    {  // load + transform this wave's queries: q = R0·s + t0 (SVGDICP.cpp:204)
+      QSlot s;
+      int64_t b = 0;
+      if (lane < nq) {
+        b = list_mode ? (int64_t)a.qlist[c0 + lane] : a.b_lo + c0 + lane;
+        const double sx = a.src[3 * b], sy = a.src[3 * b + 1], sz = a.src[3 * b + 2];
+        const double* R = a.pose.R0;
+        s.x = (sx * R[0] + sy * R[1] + sz * R[2]) + a.pose.t0[0];
+        s.y = (sx * R[3] + sy * R[4] + sz * R[5]) + a.pose.t0[1];
+        s.z = (sx * R[6] + sy * R[7] + sz * R[8]) + a.pose.t0[2];
+        s.thr = __builtin_huge_val();
+      } else {
+        s.x = s.y = s.z = 0.0;
+        s.thr = -1.0;  // nothing passes d2 <= -1
       }
-      if (any && !(a.dbg & 1)) {  // wave-uniform slow path
-        const int64_t pool_base = (q0 + q) * (int64_t)S;
-        int n = __builtin_amdgcn_readfirstlane(cnt[q]);
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          if (m[t]) {
-            if (n > S - kWave && (a.dbg & 2)) n = K;  // DEBUG: drop instead of merging
-            if (n > S - kWave) {  // make room for up to 64 new entries
-              if (lane == 0) cnt[q] = n;
-              wave_sync();
-              merge_pool(q, lane, K, S, qv, cnt, sd, si, a.pool_d, a.pool_i, pool_base);
-              n = __builtin_amdgcn_readfirstlane(cnt[q]);
-            }
-            const unsigned int lo = (unsigned int)m[t], hi = (unsigned int)(m[t] >> 32);
-            const int pos = n + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-            if ((m[t] >> lane) & 1ull) {
-              a.pool_d[pool_base + pos] = d[t];
-              a.pool_i[pool_base + pos] = a.torig[tile + t * kWave + lane];  // original target index
-            }
-            n += __popcll(m[t]);
-          }
-        }
-        if (lane == 0) cnt[q] = n;
-        wave_sync();
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) { x[t] = nx[t]; y[t] = ny[t]; z[t] = nz[t]; }
-  }
-
-  // final selection + output (ascending by (d2, idx); pad like torch::full(...,0), knn_cpu.cpp:25-26)
-  for (int q = 0; q < nq; ++q) {
-    const int64_t b = q0 + q;
-    merge_pool(q, lane, K, S, qv, cnt, sd, si, a.pool_d, a.pool_i, b * (int64_t)S);
-    const int n = __builtin_amdgcn_readfirstlane(cnt[q]);
-    for (int e = lane; e < K; e += kWave) {
-      const bool in = e < n;
-      a.out_idx[b * K + e] = in ? si[e] : 0;
-      a.out_d2[b * K + e] = in ? sd[e] : 0.0;
+      qv[lane] = s;
+      cnt[lane] = 0;
+      qb[lane] = (int)b;
     }
     wave_sync();
-  }
-}
 
-// AoS [M][3] -> permuted SoA tx/ty/tz of length Mp: slot j holds target (j·A) mod Mp (A coprime
-// with Mp), or NaN when that index is >= M (a NaN distance never passes 'd2 <= thr')
-__global__ void k_targets_soa(const double* __restrict__ tgt, int64_t M, int64_t Mp, int64_t A,
-                              double* __restrict__ tx, double* __restrict__ ty, double* __restrict__ tz,
-                              int32_t* __restrict__ torig) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= Mp) return;
-  const int64_t i = (int64_t)(((unsigned long long)j * (unsigned long long)A) % (unsigned long long)Mp);
-  const double nan = __builtin_nan("");
-  const bool in = i < M;
-  tx[j] = in ? tgt[3 * i] : nan;
-  ty[j] = in ? tgt[3 * i + 1] : nan;
-  tz[j] = in ? tgt[3 * i + 2] : nan;
-  torig[j] = (int32_t)i;
+    double x[T], y[T], z[T], nx[T], ny[T], nz[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      x[t] = a.tx[t * kWave + lane]; y[t] = a.ty[t * kWave + lane]; z[t] = a.tz[t * kWave + lane];
+    }
+    for (int64_t tile = 0; tile < a.Mp; tile += STEP) {
+      const int64_t nt = (tile + STEP < a.Mp) ? tile + STEP : tile;  // prefetch next tile (or re-read last)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        nx[t] = a.tx[nt + t * kWave + lane]; ny[t] = a.ty[nt + t * kWave + lane]; nz[t] = a.tz[nt + t * kWave + lane];
+      }
+      for (int q = 0; q < nq; ++q) {
+        const double2 q01 = *reinterpret_cast<const double2*>(&qv[q].x);
+        const double2 q23 = *reinterpret_cast<const double2*>(&qv[q].z);
+        const double qx = q01.x, qy = q01.y, qz = q23.x, thr = q23.y;
+        double d[T];
+        unsigned long long m[T];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const double dx = qx - x[t], dy = qy - y[t], dz = qz - z[t];
+          d[t] = (dx * dx + dy * dy) + dz * dz;   // knn_cpu.cpp:43-50 order, unfused
+          m[t] = __ballot(d[t] <= thr);
+          any |= m[t];
+        }
+        if (any) {  // wave-uniform slow path
+          const int64_t pool_base = (pool_row0 + q) * (int64_t)S;
+          int n = __builtin_amdgcn_readfirstlane(cnt[q]);
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            if (m[t]) {
+              if (n > S - kWave) {  // make room for up to 64 new entries
+                if (lane == 0) cnt[q] = n;
+                wave_sync();
+                merge_pool(q, lane, K, S, qv, cnt, sd, si, a.pool_d, a.pool_i, pool_base);
+                n = __builtin_amdgcn_readfirstlane(cnt[q]);
+              }
+              const unsigned int lo = (unsigned int)m[t], hi = (unsigned int)(m[t] >> 32);
+              const int pos = n + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+              if ((m[t] >> lane) & 1ull) {
+                a.pool_d[pool_base + pos] = d[t];
+                a.pool_i[pool_base + pos] = a.torig[tile + t * kWave + lane];  // original target index
+              }
+              n += __popcll(m[t]);
+            }
+          }
+          if (lane == 0) cnt[q] = n;
+          wave_sync();
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) { x[t] = nx[t]; y[t] = ny[t]; z[t] = nz[t]; }
+    }
+
+    // final selection + output (ascending by (d2, idx); pad like torch::full(...,0), knn_cpu.cpp:25-26)
+    for (int q = 0; q < nq; ++q) {
+      const int64_t b = qb[q];
+      merge_pool(q, lane, K, S, qv, cnt, sd, si, a.pool_d, a.pool_i, (pool_row0 + q) * (int64_t)S);
+      const int n = __builtin_amdgcn_readfirstlane(cnt[q]);
+      for (int e = lane; e < K; e += kWave) {
+        const bool in = e < n;
+        a.out_idx[b * K + e] = in ? si[e] : 0;
+        a.out_d2[b * K + e] = in ? sd[e] : 0.0;
+      }
+      wave_sync();
+    }
+  }
 }
 
 // target_batch = index_select(target, sourceKNN_idx) (SVGDICP.cpp:191-193), ONE copy [B][K][3]
@@ -221,31 +217,18 @@ int knn_pool_size(int K) {
   while (S < K + 128) S <<= 1;
   return S;
 }
-int64_t knn_padded_targets(int64_t M) { return ((M + STEP - 1) / STEP) * STEP; }
-
-static int64_t gcd64(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
-
-int64_t knn_stride(int64_t Mp) {
-  if (Mp <= STEP) return 1;
-  int64_t A = (int64_t)(0.6180339887498949 * (double)Mp) | 1;
-  while (gcd64(A, Mp) != 1) A += 2;
-  return A % Mp;
-}
-
-hipError_t launch_targets_soa(const double* tgt, int64_t M, int64_t Mp, double* tx, double* ty, double* tz,
-                              int32_t* torig, hipStream_t st) {
-  if (Mp <= 0) return hipSuccess;
-  const int64_t nb = (Mp + 255) / 256;
-  hipLaunchKernelGGL(k_targets_soa, dim3((unsigned)nb), dim3(256), 0, st, tgt, M, Mp, knn_stride(Mp), tx, ty, tz,
-                     torig);
-  return hipGetLastError();
-}
+int64_t knn_padded_targets(int64_t M) { return ((M + 511) / 512) * 512; }  // multiple of both kernels' steps
 
 hipError_t launch_knn_topk(const KnnArgs& a, hipStream_t st) {
-  const int64_t nq = a.b_hi - a.b_lo;
-  if (nq <= 0) return hipSuccess;
-  const int64_t nb = (nq + (int64_t)QW * WAVES - 1) / ((int64_t)QW * WAVES);
-  const size_t per_wave = sizeof(QSlot) * QW + sizeof(int) * QW + (size_t)a.S * (sizeof(double) + sizeof(int));
+  int64_t nb;
+  if (a.qlist) {
+    nb = a.list_grid;  // fixed grid; the kernel reads the list length from device memory
+  } else {
+    const int64_t nq = a.b_hi - a.b_lo;
+    if (nq <= 0) return hipSuccess;
+    nb = (nq + (int64_t)QW * WAVES - 1) / ((int64_t)QW * WAVES);
+  }
+  const size_t per_wave = sizeof(QSlot) * QW + 2 * sizeof(int) * QW + (size_t)a.S * (sizeof(double) + sizeof(int));
   const size_t smem = per_wave * WAVES;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_topk),

@@ -239,6 +239,12 @@ class _SolverBase:
                     "svnicp_get_candidates")
         return out
 
+    def get_knn_fallbacks(self) -> int:
+        """Queries the pre-filtered stage-A kernel handed to the streaming fallback (-1: streaming kernel only)."""
+        v = C.c_int(0)
+        self._check(self._L.svnicp_get_knn_fallbacks(self._h, C.byref(v)), "svnicp_get_knn_fallbacks")
+        return int(v.value)
+
     def get_candidate_dist2(self) -> np.ndarray:
         return self._getd("candidate_dist2", self._B * self._K).reshape(self._B, self._K)
 

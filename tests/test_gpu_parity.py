@@ -105,6 +105,51 @@ def test_hip_vs_oracle(hip, orc, P, B, M, K, I, full, es, thr, md, lr):
     _compare(s, o, tro, P)
 
 
+# ------------------------------------------------------------------ stage A variants
+@pytest.mark.parametrize("B,M,K", [(700, 20000, 7), (300, 9000, 1), (1000, 16384, 150), (513, 8192, 100), (64, 40000, 33)])
+def test_stage_a_prefiltered_kernel_bit_exact(hip, orc, B, M, K):
+    """knn_scan.hip (f32 pre-filter + seeded threshold): indices and dist² bit-identical to the
+    oracle's f64 brute force; the streaming kernel (SVNICP_KNN_V1=1) gives the same bits."""
+    import os
+    src, tgt = hip.scans.random_clouds(B, M, seed=B + K, extent=40.0)
+    src = src + np.array([100.0, -50.0, 3.0])      # large coordinates: the filter slack must cover them
+    tgt = tgt + np.array([100.0, -50.0, 3.0])
+    init = np.zeros((6, 2)); init[0, 1] = 0.01
+    cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
+    oi, od = orc.knn_topk(src, tgt, K)
+    res = []
+    for v1 in ("0", "1"):
+        os.environ["SVNICP_KNN_V1"] = v1
+        try:
+            s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+        finally:
+            os.environ.pop("SVNICP_KNN_V1", None)
+        fb = s.get_knn_fallbacks()
+        assert (fb == -1) == (v1 == "1")
+        assert np.array_equal(s.get_candidates().astype(np.int64), oi)
+        assert np.array_equal(s.get_candidate_dist2(), od)
+        res.append(fb)
+    assert 0 <= res[0] <= max(2, B // 100)          # the seed is good: (almost) nothing falls back
+
+
+def test_stage_a_fallback_on_pool_overflow(hip, orc):
+    """Clustered duplicates: thousands of targets at exactly the same distance overflow the
+    candidate pool of every query; all of them must be redone by the streaming fallback and still
+    come out bit-exact (ties broken by lowest index)."""
+    rng = np.random.default_rng(3)
+    centers = rng.normal(size=(6, 3)) * 5
+    tgt = np.repeat(centers, 2000, axis=0).astype(np.float32).astype(np.float64)   # M = 12000, 2000 duplicates each
+    tgt = tgt[rng.permutation(tgt.shape[0])]
+    src = (centers[rng.integers(0, 6, 300)] + rng.normal(size=(300, 3)) * 0.1)
+    init = np.zeros((6, 1))
+    cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=50, svn_full_grad=False)
+    s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+    assert s.get_knn_fallbacks() == 300
+    oi, od = orc.knn_topk(src, tgt, 50)
+    assert np.array_equal(s.get_candidates().astype(np.int64), oi)
+    assert np.array_equal(s.get_candidate_dist2(), od)
+
+
 def test_exact_ties_lowest_index_wins(hip, orc):
     """Integer-grid clouds: distances are exact and massively tied in stage A and stage B; the HIP
     path must break every tie like the reference CPU KNN (lowest index / first position)."""

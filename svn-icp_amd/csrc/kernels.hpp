@@ -88,6 +88,7 @@ struct UpdateArgs {
   double* pose_out;    // [6][P]
   int* ctl;            // [0] stop flag, [1] finish_iter
   double *trH, *trb, *trN, *trphi, *trh;  // optional traces (per-iteration slices) or nullptr
+  int h_in_lds;        // set by launch_update: per-particle H fits in LDS
 };
 size_t update_workspace_doubles(int P);
 hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose, int mode, double* R, double* t,

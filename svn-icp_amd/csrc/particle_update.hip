@@ -13,9 +13,12 @@ namespace svnicp {
 
 namespace {
 
-constexpr int UT = 1024;  // threads of the update workgroup
+constexpr int UT = 512;     // threads of the update workgroup (2 waves per SIMD: up to 256 VGPRs, no spills)
+constexpr int KREG = 32;    // pairwise-distance keys a thread keeps in registers for the median (n <= KREG*UT)
 
-// workspace layout (doubles): H[P][36] b[P][6] N[P][6] x[P][6] phi[P][6] sq[P][P]
+// HBM workspace (doubles): H[P][36] b[P][6] N[P][6] x[P][6] phi[P][6] sq[P][P].  The update kernel
+// works out of LDS copies of x, N, b (and H when it fits); HBM keeps H for the traces, sq only for
+// particle counts whose P² keys do not fit the register budget.
 struct Work {
   double *H, *b, *N, *x, *phi, *sq;
   __device__ Work(double* w, int P) {
@@ -58,24 +61,34 @@ __device__ void finalize_Hb(const double* s, const double* Rc, double* H, double
   b[5] = G[3] - G[1];
 }
 
-__device__ __forceinline__ unsigned int block_scan_incl_256(unsigned int v, unsigned int* tmp, int tid) {
-  // Hillis–Steele inclusive scan over threads 0..255 (all UT threads reach the barriers)
-  for (int off = 1; off < 256; off <<= 1) {
-    if (tid < 256) tmp[tid] = v;
-    __syncthreads();
-    if (tid < 256 && tid >= off) v += tmp[tid - off];
-    __syncthreads();
-  }
-  return v;
+// threads cooperating on one particle in the Stein-direction phase (power of two, <= 64)
+__device__ __forceinline__ int threads_per_particle(int P) {
+  int tpp = 1;
+  while (tpp < 64 && tpp * 2 * P <= UT) tpp <<= 1;
+  return tpp;
+}
+
+__device__ __forceinline__ double pair_sq(const double* lx, int i, int j) {  // SVNICP.cpp:257-260
+  double s = 0.0;
+#pragma unroll
+  for (int d = 0; d < 6; ++d) { const double df = lx[i * 6 + d] - lx[j * 6 + d]; s += df * df; }
+  return s;
 }
 
 __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
   if (a.ctl[0]) return;
+  extern __shared__ __align__(16) double dyn[];
   const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
   const int P = a.P;
   Work w(a.work, P);
+  double* lx = dyn;               // [P][6]  x = [t ; Log R]
+  double* lN = lx + 6 * P;        // [P][6]  Newton step
+  double* lb = lN + 6 * P;        // [P][6]  b
+  double* lphi = lb + 6 * P;      // [P][6]  Stein direction
+  const double* Hsrc = a.h_in_lds ? (lphi + 6 * P) : w.H;  // [P][36]
+  double* lH = a.h_in_lds ? (lphi + 6 * P) : nullptr;
   __shared__ unsigned int hist[256];
-  __shared__ unsigned int scan_tmp[256];
   __shared__ unsigned long long sel_prefix;
   __shared__ unsigned int sel_rank;
   __shared__ int nan_flag;
@@ -91,54 +104,116 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
     mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
     finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
 #pragma unroll
-    for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; }
+    for (int i = 0; i < 36; ++i) { LU[i] = H[i]; if (lH) lH[p * 36 + i] = H[i]; }
+    if (!lH || a.trH) {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) w.H[(size_t)p * 36 + i] = H[i];
+    }
     const bool ok = lu6(LU, piv);
 #pragma unroll
     for (int i = 0; i < 6; ++i) x6[i] = b[i];
     lu6_solve(LU, piv, x6);                                   // SVNICP.cpp:162
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      w.b[p * 6 + i] = b[i];
-      w.N[p * 6 + i] = ok ? x6[i] : __builtin_nan("");
+      lb[p * 6 + i] = b[i];
+      lN[p * 6 + i] = ok ? x6[i] : __builtin_nan("");
     }
     double lg[3];
     so3_log(a.R + 9 * p, lg);                                 // SVNICP.cpp:74-77
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { w.x[p * 6 + i] = a.t[3 * p + i]; w.x[p * 6 + 3 + i] = lg[i]; }
+    for (int i = 0; i < 3; ++i) { lx[p * 6 + i] = a.t[3 * p + i]; lx[p * 6 + 3 + i] = lg[i]; }
   }
+  if (tid < 256) hist[tid] = 0;
   if (tid == 0) { nan_flag = 0; sel_prefix = 0ull; sel_rank = (unsigned int)(((size_t)P * P - 1) / 2); sh_h = __builtin_nan(""); }
   __syncthreads();
 
   if (P > 1) {
-    // ---- 2. pairwise squared distances + exact lower median (torch::median, SVNICP.cpp:257-262) ----
+    // ---- 2. pairwise squared distances and mean Hessian (SVNICP.cpp:85) ----
     const int n = P * P;
-    for (int e = tid; e < n; e += UT) {
-      const int i = e / P, j = e - i * P;
-      double s = 0.0;
+    const bool keys_in_regs = n <= KREG * UT;
+    const float invP = 1.0f / (float)P;
+    unsigned long long key[KREG];
+    if (keys_in_regs) {
 #pragma unroll
-      for (int d = 0; d < 6; ++d) { const double df = w.x[i * 6 + d] - w.x[j * 6 + d]; s += df * df; }
-      w.sq[e] = s;
-      if (s != s) nan_flag = 1;
+      for (int i = 0; i < KREG; ++i) {
+        const int e = i * UT + tid;
+        key[i] = ~0ull;
+        if (e < n) {
+          int r = (int)((float)e * invP);
+          if (r * P > e) --r;
+          if ((r + 1) * P <= e) ++r;
+          const double s = pair_sq(lx, r, e - r * P);
+          key[i] = (unsigned long long)__double_as_longlong(s);
+          if (s != s) nan_flag = 1;
+        }
+      }
+    } else {
+      for (int e = tid; e < n; e += UT) {
+        const int r = e / P;
+        const double s = pair_sq(lx, r, e - r * P);
+        w.sq[e] = s;
+        if (s != s) nan_flag = 1;
+      }
+    }
+    if (!a.full_grad && tid < 36 * 8) {  // 8 lanes per entry, strided over particles, folded by shuffles
+      const int e = tid >> 3, part = tid & 7;
+      double s = 0.0;
+      for (int p = part; p < P; p += 8) s += Hsrc[(size_t)p * 36 + e];
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) s += __shfl_xor(s, off, 8);
+      if (part == 0) sh_Hmean[e] = s / P;
     }
     __syncthreads();
-    // radix select on the (non-negative) f64 bit patterns, 8 bits per pass, MSB first
+    if (!a.full_grad && wave == UT / kWave - 1 && lane < 6) {  // linalg::inv (SVNICP.cpp:225): one column per lane
+      double LU[36], col[6];
+      int piv[6];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
+      const bool ok = lu6(LU, piv);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) col[r] = (r == lane) ? 1.0 : 0.0;
+      lu6_solve(LU, piv, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) sh_Hinv[6 * r + lane] = ok ? col[r] : __builtin_nan("");
+    }
+    // ---- 3. exact lower median (torch::median, SVNICP.cpp:262): radix select on the non-negative
+    //         f64 bit patterns, 8 bits per pass; two barriers per pass, the 256-bin scan runs in wave 0 ----
     for (int pass = 7; pass >= 0; --pass) {
       const int shift = pass * 8;
-      if (tid < 256) hist[tid] = 0;
-      __syncthreads();
       const unsigned long long pre = sel_prefix;
-      for (int e = tid; e < n; e += UT) {
-        const unsigned long long key = (unsigned long long)__double_as_longlong(w.sq[e]);
-        if (pass == 7 || (key >> (shift + 8)) == pre) atomicAdd(&hist[(key >> shift) & 255ull], 1u);
+      if (keys_in_regs) {
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) {
+          const unsigned long long k = key[i];
+          if (i * UT + tid < n && (pass == 7 || (k >> (shift + 8)) == pre)) atomicAdd(&hist[(k >> shift) & 255ull], 1u);
+        }
+      } else {
+        for (int e = tid; e < n; e += UT) {
+          const unsigned long long k = (unsigned long long)__double_as_longlong(w.sq[e]);
+          if (pass == 7 || (k >> (shift + 8)) == pre) atomicAdd(&hist[(k >> shift) & 255ull], 1u);
+        }
       }
       __syncthreads();
-      const unsigned int c = tid < 256 ? hist[tid] : 0u;
-      const unsigned int incl = block_scan_incl_256(c, scan_tmp, tid);
-      const unsigned int rank = sel_rank;
-      __syncthreads();
-      if (tid < 256 && incl > rank && (incl - c) <= rank) {
-        sel_prefix = (pre << 8) | (unsigned long long)tid;
-        sel_rank = rank - (incl - c);
+      if (wave == 0) {
+        unsigned int c[4], tot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c[i] = hist[4 * lane + i]; tot += c[i]; hist[4 * lane + i] = 0; }
+        unsigned int incl = tot;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+          const unsigned int v = __shfl_up(incl, off, kWave);
+          if (lane >= off) incl += v;
+        }
+        unsigned int cum = incl - tot;  // elements in bins before mine
+        const unsigned int rank = sel_rank;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (rank >= cum && rank < cum + c[i]) {
+            sel_prefix = (pre << 8) | (unsigned long long)(4 * lane + i);
+            sel_rank = rank - cum;
+          }
+          cum += c[i];
+        }
       }
       __syncthreads();
     }
@@ -146,114 +221,118 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
       const double med = nan_flag ? __builtin_nan("") : __longlong_as_double((long long)sel_prefix);
       sh_h = med / log((double)(P + 1));                      // SVNICP.cpp:262
     }
-    if (!a.full_grad) {                                       // Hessian_mean, SVNICP.cpp:85
-      if (tid < 36) {
-        double s = 0.0;
-        for (int p = 0; p < P; ++p) s += w.H[(size_t)p * 36 + tid];
-        sh_Hmean[tid] = s / P;
-      }
-    }
-    __syncthreads();
-    if (!a.full_grad && tid == 0) {                           // linalg::inv, SVNICP.cpp:225
-      double LU[36], col[6];
-      int piv[6];
-#pragma unroll
-      for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
-      const bool ok = lu6(LU, piv);
-      for (int c = 0; c < 6; ++c) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) col[r] = (r == c) ? 1.0 : 0.0;
-        lu6_solve(LU, piv, col);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) sh_Hinv[6 * r + c] = ok ? col[r] : __builtin_nan("");
-      }
-    }
     __syncthreads();
     const double h = sh_h;
-    // ---- 3. Stein direction per particle ----
-    for (int i = 0; i < P; i += UT) {
-      const int pi = i + tid;
-      if (pi >= P) continue;
+    // ---- 4. Stein direction: TPP threads per particle split the sum over j, folded by shuffles;
+    //         the pair distance is recomputed from LDS (bit-identical, cheaper than an HBM load) ----
+    const int tpp = threads_per_particle(P);
+    const int per_pass = UT / tpp;
+    for (int base = 0; base < P; base += per_pass) {
+      const int pi = base + tid / tpp, part = tid % tpp;
+      const bool act = pi < P;
       double xi[6];
 #pragma unroll
-      for (int d = 0; d < 6; ++d) xi[d] = w.x[pi * 6 + d];
+      for (int d = 0; d < 6; ++d) xi[d] = act ? lx[pi * 6 + d] : 0.0;
       if (!a.full_grad) {                                     // svgd_grad, SVNICP.cpp:218-227
         double g[6] = {0, 0, 0, 0, 0, 0}, kn[6] = {0, 0, 0, 0, 0, 0}, ks = 0.0;
-        for (int j = 0; j < P; ++j) {
-          const double k = exp(-w.sq[(size_t)j * P + pi] / h);  // sq is exactly symmetric
+        if (act)
+          for (int j = part; j < P; j += tpp) {
+            double df[6], sq = 0.0;
 #pragma unroll
-          for (int d = 0; d < 6; ++d) {
-            g[d] += (xi[d] - w.x[j * 6 + d]) * k;
-            kn[d] += k * (-w.N[j * 6 + d]);
+            for (int d = 0; d < 6; ++d) { df[d] = xi[d] - lx[j * 6 + d]; sq += df[d] * df[d]; }
+            const double k = exp(-sq / h);
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+              g[d] += df[d] * k;
+              kn[d] += k * (-lN[j * 6 + d]);
+            }
+            ks += k;
           }
-          ks += k;
+        for (int off = tpp >> 1; off > 0; off >>= 1) {
+#pragma unroll
+          for (int d = 0; d < 6; ++d) { g[d] += __shfl_xor(g[d], off, kWave); kn[d] += __shfl_xor(kn[d], off, kWave); }
+          ks += __shfl_xor(ks, off, kWave);
         }
+        if (act && part == 0) {
 #pragma unroll
-        for (int d = 0; d < 6; ++d) g[d] = 2 / h * g[d];
+          for (int d = 0; d < 6; ++d) g[d] = 2 / h * g[d];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          double hg = 0.0;
+          for (int r = 0; r < 6; ++r) {
+            double hg = 0.0;
 #pragma unroll
-          for (int c = 0; c < 6; ++c) hg += sh_Hinv[6 * r + c] * g[c];
-          w.phi[pi * 6 + r] = (kn[r] + hg) / ks;
+            for (int c = 0; c < 6; ++c) hg += sh_Hinv[6 * r + c] * g[c];
+            lphi[pi * 6 + r] = (kn[r] + hg) / ks;
+          }
         }
       } else {                                                // svn_full_grad, SVNICP.cpp:229-252
         double Hm[36], u[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int e = 0; e < 36; ++e) Hm[e] = 0.0;
-        for (int j = 0; j < P; ++j) {
-          const double k = exp(-w.sq[(size_t)j * P + pi] / h);
-          double g[6];
+        if (act)
+          for (int j = part; j < P; j += tpp) {
+            double df[6], sq = 0.0;
 #pragma unroll
-          for (int d = 0; d < 6; ++d) g[d] = 2 / h * ((xi[d] - w.x[j * 6 + d]) * k);
-          const double k2 = k * k;
-          const double* Hj = w.H + (size_t)j * 36;
+            for (int d = 0; d < 6; ++d) { df[d] = xi[d] - lx[j * 6 + d]; sq += df[d] * df[d]; }
+            const double k = exp(-sq / h);
+            double g[6];
 #pragma unroll
-          for (int r = 0; r < 6; ++r) {
+            for (int d = 0; d < 6; ++d) g[d] = 2 / h * (df[d] * k);
+            const double k2 = k * k;
+            const double* Hj = Hsrc + (size_t)j * 36;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) Hm[6 * r + c] += k2 * Hj[6 * r + c] + g[r] * g[c];
-            u[r] += k * (-w.b[j * 6 + r]) + g[r];
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+              for (int c = 0; c < 6; ++c) Hm[6 * r + c] += k2 * Hj[6 * r + c] + g[r] * g[c];
+              u[r] += k * (-lb[j * 6 + r]) + g[r];
+            }
           }
+        for (int off = tpp >> 1; off > 0; off >>= 1) {
+#pragma unroll
+          for (int e = 0; e < 36; ++e) Hm[e] += __shfl_xor(Hm[e], off, kWave);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) u[r] += __shfl_xor(u[r], off, kWave);
         }
+        if (act && part == 0) {
 #pragma unroll
-        for (int e = 0; e < 36; ++e) Hm[e] /= P;
+          for (int e = 0; e < 36; ++e) Hm[e] /= P;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) u[r] /= P;
-        int piv[6];
-        const bool ok = lu6(Hm, piv);
-        double out[6] = {0, 0, 0, 0, 0, 0};
-        // inv(Hm)·u column by column (the reference forms the inverse, then multiplies)
-        for (int c = 0; c < 6; ++c) {
-          double col[6];
+          for (int r = 0; r < 6; ++r) u[r] /= P;
+          int piv[6];
+          const bool ok = lu6(Hm, piv);
+          double out[6] = {0, 0, 0, 0, 0, 0};
+          // inv(Hm)·u column by column (the reference forms the inverse, then multiplies)
+          for (int c = 0; c < 6; ++c) {
+            double col[6];
 #pragma unroll
-          for (int r = 0; r < 6; ++r) col[r] = (r == c) ? 1.0 : 0.0;
-          lu6_solve(Hm, piv, col);
+            for (int r = 0; r < 6; ++r) col[r] = (r == c) ? 1.0 : 0.0;
+            lu6_solve(Hm, piv, col);
 #pragma unroll
-          for (int r = 0; r < 6; ++r) out[r] += col[r] * u[c];
+            for (int r = 0; r < 6; ++r) out[r] += col[r] * u[c];
+          }
+#pragma unroll
+          for (int r = 0; r < 6; ++r) lphi[pi * 6 + r] = ok ? a.lr * out[r] : __builtin_nan("");
         }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) w.phi[pi * 6 + r] = ok ? a.lr * out[r] : __builtin_nan("");
       }
     }
   } else {
     if (tid == 0)
-      for (int d = 0; d < 6; ++d) w.phi[d] = -w.N[d];         // SVNICP.cpp:89
+      for (int d = 0; d < 6; ++d) lphi[d] = -lN[d];           // SVNICP.cpp:89
   }
   __syncthreads();
 
-  // ---- 4. traces (tests only) ----
+  // ---- 5. traces (tests only) ----
   if (a.trH) {
     for (int e = tid; e < P * 36; e += UT) a.trH[e] = w.H[e];
-    for (int e = tid; e < P * 6; e += UT) { a.trb[e] = w.b[e]; a.trN[e] = w.N[e]; a.trphi[e] = w.phi[e]; }
+    for (int e = tid; e < P * 6; e += UT) { a.trb[e] = lb[e]; a.trN[e] = lN[e]; a.trphi[e] = lphi[e]; }
     if (tid == 0) *a.trh = sh_h;
   }
 
-  // ---- 5. pose update (SVNICP.cpp:268-279) + early stop statistic ----
+  // ---- 6. pose update (SVNICP.cpp:268-279) + early stop statistic ----
   double my_norm = 0.0;
   for (int p = tid; p < P; p += UT) {
     double phi[6], dR[9], Jl[9], dt[3], Rn[9], Rdt[3], Ro[9];
 #pragma unroll
-    for (int d = 0; d < 6; ++d) phi[d] = w.phi[p * 6 + d];
+    for (int d = 0; d < 6; ++d) phi[d] = lphi[p * 6 + d];
     so3_exp(phi + 3, dR, Jl);
     mat3_vec(Jl, phi, dt);
 #pragma unroll
@@ -288,7 +367,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
   bool stop = false;
   if (a.check_early_stop) {  // block-uniform
     for (int off = 32; off > 0; off >>= 1) my_norm += __shfl_xor(my_norm, off, kWave);
-    if ((tid & 63) == 0) sh_norm[tid >> 6] = my_norm;
+    if (lane == 0) sh_norm[wave] = my_norm;
     __syncthreads();
     double m = 0.0;
     for (int i = 0; i < UT / kWave; ++i) m += sh_norm[i];
@@ -373,8 +452,19 @@ hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose
   return hipGetLastError();
 }
 
-hipError_t launch_update(const UpdateArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_particle_update, dim3(1), dim3(UT), 0, st, a);
+hipError_t launch_update(const UpdateArgs& a_in, hipStream_t st) {
+  UpdateArgs a = a_in;
+  const size_t base = (size_t)a.P * 24 * sizeof(double);           // x, N, b, phi
+  const size_t with_h = base + (size_t)a.P * 36 * sizeof(double);  // + H
+  a.h_in_lds = with_h <= 120 * 1024 ? 1 : 0;
+  const size_t smem = a.h_in_lds ? with_h : base;
+  if (smem > 150 * 1024) return hipErrorInvalidValue;  // P > 800: not supported by the one-workgroup update
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_particle_update),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_particle_update, dim3(1), dim3(UT), smem, st, a);
   return hipGetLastError();
 }
 

@@ -147,6 +147,9 @@ int svnicp_get_gpu_ms(svnicp_ctx *ctx, double out3[3]);
 /* number of queries of the last stage A that the pre-filtered kernel handed to the streaming
  * fallback (-1 when the streaming kernel ran alone) */
 int svnicp_get_knn_fallbacks(svnicp_ctx *ctx, int *out);
+/* wave steps of the last align whose float32 nearest-candidate search was not decisive and were
+ * redone in float64 (-1 when the float64 kernel ran alone) */
+int svnicp_get_ambiguous_steps(svnicp_ctx *ctx, int *out);
 /* bench hook: when on, every kernel launch of an align is bracketed by hipEvents on the
  * context's stream; svnicp_get_kernel_ms then returns the summed milliseconds and launch counts
  * per kernel class {k_knn_topk, k_build_table, k_stein_accumulate, k_reduce_partials,

@@ -56,7 +56,10 @@ struct svnicp_ctx {
   DevBuf<double> src, tgt, tx, ty, tz, pool_d, cand_d2, table, init_pose, R, t, Rtot, pose_out, sums, partial, work,
       stats, trH, trb, trN, trphi, trh;
   DevBuf<int32_t> pool_i, cand_idx, trcorr, torig, pool2, fail_list;
-  DevBuf<float> txf, tyf, tzf;
+  DevBuf<float> txf, tyf, tzf, cmaxb;
+  DevBuf<float4> tablef;
+  DevBuf<int> ambig;
+  bool accum_f32 = true;
   DevBuf<unsigned long long> emax;
   DevBuf<int> fail_count;
   bool use_scan = false;   // stage A through knn_scan.hip (f32 pre-filter) with knn_topk.hip as fallback
@@ -176,7 +179,7 @@ void svnicp_destroy(svnicp_ctx* c) {
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
   for (auto* b : dbl) b->release();
-  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->pev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -307,11 +310,19 @@ int svnicp_align_begin(svnicp_ctx* c) {
   HIPCHK(c, c->cand_idx.ensure((size_t)B * c->K));
   HIPCHK(c, c->cand_d2.ensure((size_t)B * c->K));
   HIPCHK(c, c->table.ensure((size_t)B * c->K * 3));
+  {
+    const char* v1 = getenv("SVNICP_ACCUM_V1");  // A/B switch for tests and profiling
+    c->accum_f32 = !(v1 && v1[0] == '1');
+  }
+  HIPCHK(c, c->tablef.ensure((size_t)B * c->K));
+  HIPCHK(c, c->cmaxb.ensure((size_t)B));
+  HIPCHK(c, c->ambig.ensure(1));
+  HIPCHK(c, hipMemsetAsync(c->ambig.p, 0, sizeof(int), c->stream));
   HIPCHK(c, c->history.ensure((size_t)(I > 0 ? I : 1) * 6 * P));
   c->hist_I = I; c->hist_P = P;
   const int nshard = c->p_hi - c->p_lo;
   if (nshard > 0) {
-    c->plan = plan_accumulate(nshard, B, c->K, c->num_cus);
+    c->plan = plan_accumulate(nshard, B, c->K, c->num_cus, c->accum_f32);
     HIPCHK(c, c->partial.ensure((size_t)c->plan.grid_x * c->plan.Ppad * kNSums));
   }
   if (c->prm.record_trace) {
@@ -377,7 +388,7 @@ int svnicp_build_candidate_table(svnicp_ctx* c) {
   if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_build_candidate_table: call svnicp_align_begin first");
   if (bind(c)) return SVNICP_ERR_HIP;
   HIPCHK(c, prof_begin(c, KC_TABLE));
-  HIPCHK(c, launch_build_table(c->cand_idx.p, c->B * (int64_t)c->K, c->tgt.p, c->table.p, c->stream));
+  HIPCHK(c, launch_build_table2(c->cand_idx.p, c->B, c->K, c->tgt.p, c->table.p, c->tablef.p, c->cmaxb.p, c->stream));
   HIPCHK(c, prof_end(c));
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   c->have_candidates = true;
@@ -393,7 +404,8 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   if (nshard <= 0) return SVNICP_OK;
   if (bind(c)) return SVNICP_ERR_HIP;
   AccumArgs a{};
-  a.src = c->src.p; a.table = c->table.p; a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K;
+  a.src = c->src.p; a.table = c->table.p; a.tablef = c->tablef.p; a.cmax = c->cmaxb.p; a.ambig_count = c->ambig.p;
+  a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K;
   a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
   a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;
   HIPCHK(c, prof_begin(c, KC_ACCUM));
@@ -531,6 +543,13 @@ int svnicp_get_knn_fallbacks(svnicp_ctx* c, int* out) {
   if (!c->have_candidates) return fail(c, SVNICP_ERR_INVALID, "no candidates yet");
   if (!c->use_scan) { *out = -1; return SVNICP_OK; }
   return fetch(c, out, c->fail_count.p, sizeof(int));
+}
+
+int svnicp_get_ambiguous_steps(svnicp_ctx* c, int* out) {
+  CTX_CHECK(c);
+  if (!c->have_result) return fail(c, SVNICP_ERR_INVALID, "no registration result yet");
+  if (!c->accum_f32) { *out = -1; return SVNICP_OK; }
+  return fetch(c, out, c->ambig.p, sizeof(int));
 }
 
 int svnicp_set_profile(svnicp_ctx* c, int on) {

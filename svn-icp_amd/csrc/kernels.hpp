@@ -53,7 +53,10 @@ hipError_t launch_build_table(const int32_t* idx, int64_t n_entries, const doubl
 // ---------------- Stage B (stein_iter.hip) ----------------
 struct AccumArgs {
   const double* src;    // [B][3]
-  const double* table;  // [B][K][3] candidate coordinates
+  const double* table;  // [B][K][3] candidate coordinates (f64, absolute)
+  const float4* tablef; // [B][K] float32 local coordinates + |c'|² (fast variant)
+  const float* cmax;    // [B] max |c'| per source point (fast variant)
+  int* ambig_count;     // optional statistic: wave steps that took the exact path, or nullptr
   const double* Rtot;   // [P][12]: R_total row-major (9) + t_total (3)
   int64_t B;
   int K, RS;            // RS = LDS row stride in doubles (odd)
@@ -67,8 +70,10 @@ struct AccumArgs {
   const int* ctl;       // ctl[0] = stop flag
   int32_t* corr;        // optional trace [P][B] (this iteration), or nullptr
 };
-struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS; int64_t n_tiles; size_t smem; };
-AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus);
+struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32; int64_t n_tiles; size_t smem; };
+AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, bool f32);
+hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, double* table, float4* tablef,
+                               float* cmax, hipStream_t st);
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles,
                                   double* sums, const int* ctl, hipStream_t st);

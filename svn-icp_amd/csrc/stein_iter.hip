@@ -161,6 +161,250 @@ __global__ __launch_bounds__(NT) void k_stein_accumulate(AccumArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast variant: float32 search in local coordinates, exact float64 finish.
+//
+// For source point b let a_b = its first candidate.  k_build_table2 stores every candidate as
+// c' = fl32(c − a_b) and cc = fl32(|c'|²) (16 B), plus C_b = max |c'|∞.  For a particle with
+// x' = fl32(T_p(s_b) − a_b) the score  S_k = fma(c'z,mz, fma(c'y,my, fma(c'x,mx, cc))),  m = −2x',
+// approximates d²_k − |x'|², so argmin_k S_k is the nearest candidate unless two scores are closer
+// than the rounding error.  Bound (u = 2^-24, C = C_b, X = |x'|∞):
+//   |cc − |c'|²_real| <= 10uC²,  cross-term inputs 12.6uXC,  three fma roundings 3u(3C²+6XC)
+//   => |S_k − s_k| <= 19.1uC² + 30.8uXC  <  EPS := 40·u·C·(C+X).
+// A lane keeps (min, argmin, second-min) of S; if second-min − min > 2·EPS its argmin is the
+// exact f64 argmin (every other candidate is strictly farther in exact arithmetic, so the
+// reference's first-index tie rule cannot matter).  Otherwise — exact ties, padded duplicates,
+// overflow/NaN — the wave step re-runs the exact f64 loop of the baseline kernel on the f64 table.
+// The winner's d², mask, weight and the 22 sums are computed in f64 exactly as in the baseline
+// kernel, so correspondences and sums are bit-identical to it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rdlane_f64(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// one (particle, source point) result waiting for its winner's f64 coordinates
+struct Pending {
+  double T0, T1, T2;   // transformed source point
+  double q0, q1, q2;   // winner candidate (f64), loaded one search-loop ago
+  int pt;              // point index inside the tile (source point re-read from LDS)
+};
+
+__device__ __forceinline__ void accumulate_point(const Pending& pd, const double* spts, double max_dist, double* acc) {
+  const double dx = pd.T0 - pd.q0, dy = pd.T1 - pd.q1, dz = pd.T2 - pd.q2;
+  const double best = (dx * dx + dy * dy) + dz * dz;   // exact d² of the winner (knn_cpu.cpp:43-50 order)
+  double w = 1.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
+  if (best < max_dist) {  // point_filter, SVGDICP.cpp:331-333
+    const double n = sqrt(best);                        // SVNICP.cpp:120
+    const double wq = max_dist / (max_dist + 3 * n);
+    w = wq * wq;                                        // SVNICP.cpp:122
+    e0 = w * dx; e1 = w * dy; e2 = w * dz;              // SVNICP.cpp:119,123
+    n0 = spts[3 * pd.pt]; n1 = spts[3 * pd.pt + 1]; n2 = spts[3 * pd.pt + 2];
+  }
+  const double w0 = w * n0, w1 = w * n1, w2 = w * n2;
+  acc[0] += w;
+  acc[1] += w0; acc[2] += w1; acc[3] += w2;
+  acc[4] = fma(w0, n0, acc[4]); acc[5] = fma(w0, n1, acc[5]); acc[6] = fma(w0, n2, acc[6]);
+  acc[7] = fma(w1, n1, acc[7]); acc[8] = fma(w1, n2, acc[8]); acc[9] = fma(w2, n2, acc[9]);
+  acc[10] += e0; acc[11] += e1; acc[12] += e2;
+  acc[13] = fma(e0, n0, acc[13]); acc[14] = fma(e0, n1, acc[14]); acc[15] = fma(e0, n2, acc[15]);
+  acc[16] = fma(e1, n0, acc[16]); acc[17] = fma(e1, n1, acc[17]); acc[18] = fma(e1, n2, acc[18]);
+  acc[19] = fma(e2, n0, acc[19]); acc[20] = fma(e2, n1, acc[20]); acc[21] = fma(e2, n2, acc[21]);
+}
+
+template <int PW, int WP>
+__global__ __launch_bounds__(NT) void k_stein_accumulate_f32(AccumArgs a) {
+  if (a.ctl[0]) return;
+  constexpr int BW = kWave / PW;
+  constexpr int WB = 4 / WP;
+  extern __shared__ __align__(16) double lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  const int wp = wave % WP, wb = wave / WP;
+  const int pl = lane % PW, bs = lane / PW;
+  const int pidx = blockIdx.y * (WP * PW) + wp * PW + pl;
+  const int p = a.p_lo + pidx;
+  const bool pvalid = p < a.p_hi;
+
+  double Rt[9], tt[3];
+  {
+    const double* rp = a.Rtot + 12 * (size_t)(pvalid ? p : a.p_lo);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rt[i] = rp[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tt[i] = rp[9 + i];
+  }
+  double acc[kNSums];
+#pragma unroll
+  for (int i = 0; i < kNSums; ++i) acc[i] = 0.0;
+
+  const int K = a.K, TP = a.TP;
+  const int Kp = (K + 3) & ~3;  // LDS row length: padded to a multiple of 4 with never-selected sentinels
+  // LDS: rows [TP][Kp] float4 (+4 slack for the prefetch) | spts [TP][3] f64 | anch [TP][3] f64 | cmax [TP] f32
+  float4* rows = reinterpret_cast<float4*>(lds);
+  double* spts = reinterpret_cast<double*>(rows + (size_t)TP * Kp + 4);
+  double* anch = spts + 3 * TP;
+  float* cmx = reinterpret_cast<float*>(anch + 3 * TP);
+  const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_block;
+  const int64_t tile1 = (tile0 + a.tiles_per_block < a.n_tiles) ? tile0 + a.tiles_per_block : a.n_tiles;
+  const float kEpsScale = 40.0f * 5.9604644775390625e-08f;
+
+  for (int64_t tile = tile0; tile < tile1; ++tile) {
+    const int64_t b0 = tile * TP;
+    const int npts = (a.B - b0) < TP ? (int)(a.B - b0) : TP;
+    __syncthreads();
+    {
+      const float4* g = a.tablef + (size_t)b0 * K;
+      const int total = TP * Kp + 4;
+      const float4 sentinel = make_float4(0.f, 0.f, 0.f, __builtin_huge_valf());
+      int r = tid / Kp, c = tid - r * Kp;
+      for (int e = tid; e < total; e += NT) {
+        rows[e] = (r < npts && c < K) ? g[(size_t)r * K + c] : sentinel;
+        c += NT;
+        while (c >= Kp) { c -= Kp; ++r; }
+      }
+      const double* gs = a.src + 3 * (size_t)b0;
+      for (int e = tid; e < npts * 3; e += NT) spts[e] = gs[e];
+      for (int e = tid; e < npts; e += NT) {
+        const double* c0 = a.table + (size_t)(b0 + e) * K * 3;
+        anch[3 * e] = c0[0]; anch[3 * e + 1] = c0[1]; anch[3 * e + 2] = c0[2];
+        cmx[e] = a.cmax[b0 + e];
+      }
+    }
+    __syncthreads();
+
+    Pending pend;
+    bool have = false;
+    for (int pt = wb * BW + bs; pt < TP; pt += WB * BW) {
+      const bool valid = pvalid && (pt < npts);
+      const double s0 = spts[3 * pt], s1 = spts[3 * pt + 1], s2 = spts[3 * pt + 2];
+      const double T0 = (s0 * Rt[0] + s1 * Rt[1] + s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64
+      const double T1 = (s0 * Rt[3] + s1 * Rt[4] + s2 * Rt[5]) + tt[1];
+      const double T2 = (s0 * Rt[6] + s1 * Rt[7] + s2 * Rt[8]) + tt[2];
+      const float xf0 = (float)(T0 - anch[3 * pt]), xf1 = (float)(T1 - anch[3 * pt + 1]), xf2 = (float)(T2 - anch[3 * pt + 2]);
+      const float m0 = -2.0f * xf0, m1 = -2.0f * xf1, m2 = -2.0f * xf2;
+      const float4* row = rows + (size_t)pt * Kp;
+      float best1 = __builtin_huge_valf(), best2 = __builtin_huge_valf();
+      int kb = 0;
+      float4 c0 = row[0], c1 = row[1], c2 = row[2], c3 = row[3];
+      for (int k = 0; k < Kp; k += 4) {
+        const float4 n0 = row[k + 4], n1 = row[k + 5], n2 = row[k + 6], n3 = row[k + 7];  // prefetch (slack at the end)
+        const float sA = __builtin_fmaf(c0.z, m2, __builtin_fmaf(c0.y, m1, __builtin_fmaf(c0.x, m0, c0.w)));
+        const float sB = __builtin_fmaf(c1.z, m2, __builtin_fmaf(c1.y, m1, __builtin_fmaf(c1.x, m0, c1.w)));
+        const float sC = __builtin_fmaf(c2.z, m2, __builtin_fmaf(c2.y, m1, __builtin_fmaf(c2.x, m0, c2.w)));
+        const float sD = __builtin_fmaf(c3.z, m2, __builtin_fmaf(c3.y, m1, __builtin_fmaf(c3.x, m0, c3.w)));
+        bool lt;
+        lt = sA < best1; best2 = __builtin_amdgcn_fmed3f(best1, best2, sA); best1 = __builtin_fminf(best1, sA); kb = lt ? k : kb;
+        lt = sB < best1; best2 = __builtin_amdgcn_fmed3f(best1, best2, sB); best1 = __builtin_fminf(best1, sB); kb = lt ? k + 1 : kb;
+        lt = sC < best1; best2 = __builtin_amdgcn_fmed3f(best1, best2, sC); best1 = __builtin_fminf(best1, sC); kb = lt ? k + 2 : kb;
+        lt = sD < best1; best2 = __builtin_amdgcn_fmed3f(best1, best2, sD); best1 = __builtin_fminf(best1, sD); kb = lt ? k + 3 : kb;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      }
+      const float X = __builtin_fmaxf(__builtin_fabsf(xf0), __builtin_fmaxf(__builtin_fabsf(xf1), __builtin_fabsf(xf2)));
+      const float C = cmx[pt];
+      const float eps2 = 2.0f * kEpsScale * C * (C + X);
+      const bool ambiguous = valid && !(best2 - best1 > eps2);
+      const int64_t b = b0 + pt;
+      const double* drow = a.table + (size_t)(valid ? b : b0) * K * 3;
+      unsigned long long am = __ballot(ambiguous);
+      if (am) {  // rare: exact f64 nearest-of-K for the undecided lanes, candidate-parallel across the wave
+        if (a.ambig_count && lane == 0) atomicAdd(a.ambig_count, 1);
+        do {
+          const int L = (int)__builtin_ctzll(am);
+          am &= am - 1;
+          const double t0 = rdlane_f64(T0, L), t1 = rdlane_f64(T1, L), t2 = rdlane_f64(T2, L);
+          const int ptL = __builtin_amdgcn_readlane(pt, L);
+          const double* r = a.table + (size_t)(b0 + ptL) * K * 3;
+          double bd = __builtin_huge_val(), d_first = 0.0;
+          int bk = 0x7fffffff;
+          for (int k = lane; k < K; k += kWave) {
+            const double dx = t0 - r[3 * k], dy = t1 - r[3 * k + 1], dz = t2 - r[3 * k + 2];
+            const double d = (dx * dx + dy * dy) + dz * dz;   // knn_cpu.cpp:43-50 order, unfused
+            if (k == 0) d_first = d;
+            if (d < bd || (d == bd && k < bk)) { bd = d; bk = k; }
+          }
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_xor(bd, off, kWave);
+            const int ok = __shfl_xor(bk, off, kWave);
+            if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
+          }
+          // the serial reference loop starts from candidate 0 and only replaces on '<': a NaN first
+          // distance is never replaced, and an all-NaN row keeps index 0
+          const double d0 = rdlane_f64(d_first, 0);
+          const int ke = (d0 != d0 || bk == 0x7fffffff) ? 0 : bk;
+          if (lane == L) kb = ke;
+        } while (am);
+      }
+      if (a.corr && valid) a.corr[(size_t)p * a.B + b] = kb;
+      // software pipeline: start the gather of this point's winner, then finish the previous point
+      // (whose winner was requested one search loop ago)
+      Pending cur;
+      cur.T0 = T0; cur.T1 = T1; cur.T2 = T2; cur.pt = valid ? pt : -1;
+      cur.q0 = drow[3 * kb]; cur.q1 = drow[3 * kb + 1]; cur.q2 = drow[3 * kb + 2];
+      if (have && pend.pt >= 0) accumulate_point(pend, spts, a.max_dist, acc);
+      pend = cur;
+      have = true;
+    }
+    if (have && pend.pt >= 0) accumulate_point(pend, spts, a.max_dist, acc);  // drain before the tile is replaced
+  }
+
+#pragma unroll
+  for (int off = PW; off < kWave; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < kNSums; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
+  }
+  if constexpr (WB > 1) {
+    __syncthreads();
+    double* red = lds;
+    if (wb > 0 && bs == 0) {
+      double* r = red + ((size_t)(wb - 1) * (WP * PW) + wp * PW + pl) * kNSums;
+#pragma unroll
+      for (int i = 0; i < kNSums; ++i) r[i] = acc[i];
+    }
+    __syncthreads();
+    if (wb == 0 && bs == 0) {
+      for (int o = 0; o < WB - 1; ++o) {
+        const double* r = red + ((size_t)o * (WP * PW) + wp * PW + pl) * kNSums;
+#pragma unroll
+        for (int i = 0; i < kNSums; ++i) acc[i] += r[i];
+      }
+    }
+  }
+  if (wb == 0 && bs == 0) {
+    double* out = a.partial + ((size_t)blockIdx.x * a.Ppad + pidx) * kNSums;
+#pragma unroll
+    for (int i = 0; i < kNSums; ++i) out[i] = acc[i];
+  }
+}
+
+// candidate table: f64 absolute coordinates (target_batch = index_select(target, sourceKNN_idx),
+// SVGDICP.cpp:191-193, ONE copy), float32 local coordinates + |c'|², and C_b.  One wave per row.
+__global__ __launch_bounds__(256) void k_build_table2(const int32_t* __restrict__ idx, int64_t B, int K,
+                                                      const double* __restrict__ tgt, double* __restrict__ table,
+                                                      float4* __restrict__ tablef, float* __restrict__ cmax) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int64_t i0 = idx[b * K];
+  const double a0 = tgt[3 * i0], a1 = tgt[3 * i0 + 1], a2 = tgt[3 * i0 + 2];
+  float cm = 0.0f;
+  for (int k = lane; k < K; k += kWave) {
+    const int64_t i = idx[b * K + k];
+    const double x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
+    double* o = table + ((size_t)b * K + k) * 3;
+    o[0] = x; o[1] = y; o[2] = z;
+    const float cx = (float)(x - a0), cy = (float)(y - a1), cz = (float)(z - a2);
+    const float cc = (float)(((double)cx * cx + (double)cy * cy) + (double)cz * cz);
+    tablef[(size_t)b * K + k] = make_float4(cx, cy, cz, cc);
+    cm = __builtin_fmaxf(cm, __builtin_fmaxf(__builtin_fabsf(cx), __builtin_fmaxf(__builtin_fabsf(cy), __builtin_fabsf(cz))));
+  }
+  for (int off = 32; off > 0; off >>= 1) cm = __builtin_fmaxf(cm, __shfl_xor(cm, off, kWave));
+  if (lane == 0) cmax[b] = cm;   // NaN coordinates give NaN scores => every step takes the exact path
+}
+
 // sums[p_lo + i][s] = Σ_blk partial[blk][i][s], block order fixed.  Workgroup = 16 entries × 16
 // block lanes; each block lane walks blk = bl, bl+16, … and the 16 lanes are folded in order.
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, int nblk, int Ppad,
@@ -188,7 +432,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
 
 template <int PW, int WP>
 hipError_t launch_t(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
-  auto kern = k_stein_accumulate<PW, WP>;
+  auto kern = plan.f32 ? k_stein_accumulate_f32<PW, WP> : k_stein_accumulate<PW, WP>;
   if (plan.smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.smem);
@@ -200,8 +444,26 @@ hipError_t launch_t(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
 
 }  // namespace
 
-AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus) {
+template <int PW, int WP>
+static int occ_t(const AccumPlan& pl) {
+  int n = 0;
+  hipError_t e = pl.f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_accumulate_f32<PW, WP>, NT, pl.smem)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_accumulate<PW, WP>, NT, pl.smem);
+  if (e != hipSuccess || n < 1) n = 2;
+  return n > 8 ? 8 : n;
+}
+static int occupancy_blocks(const AccumPlan& pl) {
+  switch (pl.PW) {
+    case 8: return occ_t<8, 1>(pl);
+    case 16: return occ_t<16, 1>(pl);
+    case 32: return occ_t<32, 1>(pl);
+    default: return pl.WP == 1 ? occ_t<64, 1>(pl) : pl.WP == 2 ? occ_t<64, 2>(pl) : occ_t<64, 4>(pl);
+  }
+}
+
+AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, bool f32) {
   AccumPlan pl{};
+  pl.f32 = f32 ? 1 : 0;
   int PW = 8;
   while (PW < 64 && PW < n_particles) PW <<= 1;
   int WP = 1;
@@ -213,15 +475,19 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus) {
   const int BW = 64 / PW, WB = 4 / WP;
   const int pass = BW * WB;                  // points per workgroup pass
   pl.RS = (3 * K) | 1;
+  // bytes per staged source point: baseline = padded f64 row + point; f32 variant = K float4 + point + anchor + C_b
+  const size_t per_pt = f32 ? ((size_t)((K + 3) & ~3) * 16 + 24 + 24 + 4) : ((size_t)(pl.RS + 3) * 8);
   int TP = pass;
   while (TP < 16) TP += pass;                // at least 16 points per tile …
-  while (TP > pass && (size_t)TP * (pl.RS + 3) * 8 > 60 * 1024) TP -= pass;  // … within ~60 KB
+  while (TP > pass && (size_t)TP * per_pt > (f32 ? 32u : 60u) * 1024) TP -= pass;  // … within a modest LDS footprint
   pl.TP = TP;
-  const size_t tile_bytes = (size_t)TP * (pl.RS + 3) * sizeof(double);
+  const size_t tile_bytes = (size_t)TP * per_pt + 4 * 16 + 16;
   const size_t red_bytes = (size_t)(WB - 1) * per_wg * kNSums * sizeof(double);
   pl.smem = tile_bytes > red_bytes ? tile_bytes : red_bytes;
   pl.n_tiles = (B + TP - 1) / TP;
-  int64_t want = (int64_t)num_cus * 4 / (pl.grid_y > 0 ? pl.grid_y : 1);  // ≈4 workgroups per CU in total
+  // one resident round of workgroups: a second, partial round would leave most of the chip idle
+  const int wg_per_cu = occupancy_blocks(pl);
+  int64_t want = (int64_t)num_cus * wg_per_cu / (pl.grid_y > 0 ? pl.grid_y : 1);
   if (want < 1) want = 1;
   int64_t gx = pl.n_tiles < want ? pl.n_tiles : want;
   if (gx < 1) gx = 1;
@@ -244,6 +510,13 @@ hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st)
       if (plan.WP == 2) return launch_t<64, 2>(plan, a, st);
       return launch_t<64, 4>(plan, a, st);
   }
+}
+
+hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, double* table, float4* tablef,
+                               float* cmax, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_build_table2, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, idx, B, K, tgt, table, tablef, cmax);
+  return hipGetLastError();
 }
 
 hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles,

@@ -245,6 +245,12 @@ class _SolverBase:
         self._check(self._L.svnicp_get_knn_fallbacks(self._h, C.byref(v)), "svnicp_get_knn_fallbacks")
         return int(v.value)
 
+    def get_ambiguous_steps(self) -> int:
+        """Wave steps whose float32 nearest-of-K search had to be redone in float64 (-1: f64 kernel only)."""
+        v = C.c_int(0)
+        self._check(self._L.svnicp_get_ambiguous_steps(self._h, C.byref(v)), "svnicp_get_ambiguous_steps")
+        return int(v.value)
+
     def get_candidate_dist2(self) -> np.ndarray:
         return self._getd("candidate_dist2", self._B * self._K).reshape(self._B, self._K)
 

@@ -12,5 +12,5 @@ prm = pkg.SteinICPParam(iterations=I, lr=1.0, max_dist=1.0, KNN_count=100, SVN_f
 s = pkg.SVNICP(prm, init); s.set_profile(True)
 for rep in range(3):
     s.add_cloud(pair.source, pair.target, init); s.set_initial_mean(np.eye(4)); s.stein_align()
-    print({k: round(v[0], 3) for k, v in s.get_kernel_ms().items()}, s.get_gpu_ms().round(2), "fallbacks", s.get_knn_fallbacks(), flush=True)
+    print({k: round(v[0], 3) for k, v in s.get_kernel_ms().items()}, s.get_gpu_ms().round(2), "fallbacks", s.get_knn_fallbacks(), "ambiguous wave-steps", s.get_ambiguous_steps(), flush=True)
 print("mean", s.get_transformation())

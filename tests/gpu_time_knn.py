@@ -14,3 +14,6 @@ for rep in range(3):
     s.add_cloud(pair.source, pair.target, init); s.set_initial_mean(np.eye(4)); s.stein_align()
     print({k: round(v[0], 3) for k, v in s.get_kernel_ms().items()}, s.get_gpu_ms().round(2), "fallbacks", s.get_knn_fallbacks(), "ambiguous wave-steps", s.get_ambiguous_steps(), flush=True)
 print("mean", s.get_transformation())
+h = s.get_particle_history().reshape(I, 6, P)
+print("particle std per iteration (x, yaw):", [ (round(float(h[i,0].std()),4), round(float(h[i,5].std()),5)) for i in range(0, I, 2)])
+print("max |x - mean| per iteration:", [round(float(np.abs(h[i,0]-h[i,0].mean()).max()),4) for i in range(0,I,2)])

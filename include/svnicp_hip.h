@@ -147,6 +147,9 @@ int svnicp_get_gpu_ms(svnicp_ctx *ctx, double out3[3]);
 /* number of queries of the last stage A that the pre-filtered kernel handed to the streaming
  * fallback (-1 when the streaming kernel ran alone) */
 int svnicp_get_knn_fallbacks(svnicp_ctx *ctx, int *out);
+/* per source point: how many targets survived the float32 pre-filter of the pruned stage-A kernel
+ * (needs params.record_trace) */
+int svnicp_get_knn_survivors(svnicp_ctx *ctx, int32_t *outB);
 /* wave steps of the last align whose float32 nearest-candidate search was not decisive and were
  * redone in float64 (-1 when the float64 kernel ran alone) */
 int svnicp_get_ambiguous_steps(svnicp_ctx *ctx, int *out);

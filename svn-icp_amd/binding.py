@@ -81,6 +81,7 @@ def load_library():
     L.svnicp_get_candidates.argtypes = [vp, ip]
     L.svnicp_get_trace.argtypes = [vp, ip, dp, dp, dp, dp, dp]
     L.svnicp_get_knn_fallbacks.argtypes = [vp, C.POINTER(C.c_int)]
+    L.svnicp_get_knn_survivors.argtypes = [vp, ip]
     L.svnicp_get_ambiguous_steps.argtypes = [vp, C.POINTER(C.c_int)]
     L.svnicp_set_profile.argtypes = [vp, C.c_int]
     L.svnicp_get_kernel_ms.argtypes = [vp, dp, ip]

@@ -62,6 +62,15 @@ struct svnicp_ctx {
   bool accum_f32 = true;
   DevBuf<unsigned long long> emax;
   DevBuf<int> fail_count;
+  // stage A variant: 0 = streaming only (knn_topk), 1 = seeded f32 scan (knn_scan), 2 = pruned tiles (knn_tiles)
+  int knn_variant = 0;
+  int target_layout = -1;  // what the SoA currently holds: 0 hashed order, 1 Morton tiles, -1 nothing
+  DevBuf<unsigned int> keys_a, keys_b;
+  DevBuf<int32_t> vals_a, order_t, qorder, stat_n;
+  DevBuf<unsigned long long> bbox;
+  DevBuf<float> tile_box;
+  DevBuf<unsigned char> sort_tmp;
+  size_t sort_tmp_bytes = 0;
   bool use_scan = false;   // stage A through knn_scan.hip (f32 pre-filter) with knn_topk.hip as fallback
   int64_t scan_Ms = 0; int scan_rank = 0, scan_S2 = 0;
   DevBuf<float> history;
@@ -76,7 +85,8 @@ struct svnicp_ctx {
   size_t pused = 0;
 };
 
-constexpr int kFallbackGrid = 16;  // workgroups of the streaming kernel when it only redoes failed queries
+constexpr int kFallbackGrid = 256;  // workgroups of the streaming kernel when it only redoes failed queries
+constexpr int kFallbackQW = 2;      // … two queries per wave, so a few hundred failures still run in parallel
 
 enum { KC_KNN = 0, KC_TABLE = 1, KC_ACCUM = 2, KC_REDUCE = 3, KC_UPDATE = 4, KC_COUNT = 5 };
 
@@ -179,6 +189,7 @@ void svnicp_destroy(svnicp_ctx* c) {
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
   for (auto* b : dbl) b->release();
+  c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
   c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->pev) (void)hipEventDestroy(e);
@@ -210,16 +221,7 @@ int svnicp_set_clouds(svnicp_ctx* c, const double* src, int64_t B, const double*
   HIPCHK(c, hipMemcpyAsync(c->src.p, src, (size_t)B * 24, kind, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->tgt.p, tgt, (size_t)M * 24, kind, c->stream));
   c->B = B; c->M = M; c->Mp = knn_padded_targets(M);
-  HIPCHK(c, c->tx.ensure((size_t)c->Mp));
-  HIPCHK(c, c->ty.ensure((size_t)c->Mp));
-  HIPCHK(c, c->tz.ensure((size_t)c->Mp));
-  HIPCHK(c, c->torig.ensure((size_t)c->Mp));
-  HIPCHK(c, c->txf.ensure((size_t)c->Mp));
-  HIPCHK(c, c->tyf.ensure((size_t)c->Mp));
-  HIPCHK(c, c->tzf.ensure((size_t)c->Mp));
-  HIPCHK(c, c->emax.ensure(1));
-  HIPCHK(c, launch_targets_soa2(c->tgt.p, M, c->Mp, c->tx.p, c->ty.p, c->tz.p, c->txf.p, c->tyf.p,
-                                c->tzf.p, c->torig.p, c->emax.p, c->stream));
+  c->target_layout = -1;  // the SoA copies are (re)built in svnicp_align_begin, once K is final
   if (mem_kind != SVNICP_MEM_DEVICE) HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse its host buffers
   c->clouds_set = true;
   c->have_candidates = false;
@@ -283,6 +285,44 @@ int svnicp_set_shard(svnicp_ctx* c, int p_lo, int p_hi) {
   return SVNICP_OK;
 }
 
+// (re)build the target SoA copies in the order the chosen stage-A kernel wants
+static int ensure_target_layout(svnicp_ctx* c) {
+  const char* force = getenv("SVNICP_KNN");  // A/B switch for tests and profiling: v1 | v2 | v3
+  int want = 0;
+  if (knn_tiles_applicable(c->Mp, c->K)) want = 2;
+  else if (knn_scan_plan(c->Mp, c->K, &c->scan_Ms, &c->scan_rank, &c->scan_S2)) want = 1;
+  if (force && !strcmp(force, "v1")) want = 0;
+  if (force && !strcmp(force, "v2")) want = knn_scan_plan(c->Mp, c->K, &c->scan_Ms, &c->scan_rank, &c->scan_S2) ? 1 : 0;
+  c->knn_variant = want;
+  c->use_scan = want == 1;
+  const int layout = want == 2 ? 1 : 0;
+  if (c->target_layout == layout) return 0;
+  const int64_t M = c->M, Mp = c->Mp;
+  HIPCHK(c, c->tx.ensure((size_t)Mp)); HIPCHK(c, c->ty.ensure((size_t)Mp)); HIPCHK(c, c->tz.ensure((size_t)Mp));
+  HIPCHK(c, c->txf.ensure((size_t)Mp)); HIPCHK(c, c->tyf.ensure((size_t)Mp)); HIPCHK(c, c->tzf.ensure((size_t)Mp));
+  HIPCHK(c, c->torig.ensure((size_t)Mp));
+  HIPCHK(c, c->emax.ensure(1));
+  if (layout == 0) {
+    HIPCHK(c, launch_targets_soa2(c->tgt.p, M, Mp, c->tx.p, c->ty.p, c->tz.p, c->txf.p, c->tyf.p, c->tzf.p, c->torig.p,
+                                  c->emax.p, c->stream));
+  } else {
+    const size_t nmax = (size_t)(M > c->B ? M : c->B);
+    HIPCHK(c, c->keys_a.ensure(nmax)); HIPCHK(c, c->keys_b.ensure(nmax)); HIPCHK(c, c->vals_a.ensure(nmax));
+    HIPCHK(c, c->order_t.ensure((size_t)M)); HIPCHK(c, c->qorder.ensure((size_t)c->B));
+    HIPCHK(c, c->bbox.ensure(6));
+    HIPCHK(c, c->tile_box.ensure((size_t)6 * (Mp / 512)));
+    const size_t tb = sort_temp_bytes(nmax);
+    if (tb > c->sort_tmp_bytes) { HIPCHK(c, c->sort_tmp.ensure(tb)); c->sort_tmp_bytes = tb; }
+    HIPCHK(c, launch_bbox(c->tgt.p, M, c->bbox.p, c->stream));
+    HIPCHK(c, launch_morton_order(c->tgt.p, 0, M, 0, c->pose0, c->bbox.p, c->keys_a.p, c->keys_b.p, c->vals_a.p,
+                                  c->order_t.p, c->sort_tmp.p, c->sort_tmp_bytes, c->stream));
+    HIPCHK(c, launch_targets_sorted(c->tgt.p, M, Mp, c->order_t.p, c->tx.p, c->ty.p, c->tz.p, c->txf.p, c->tyf.p, c->tzf.p,
+                                    c->torig.p, c->tile_box.p, c->emax.p, c->stream));
+  }
+  c->target_layout = layout;
+  return 0;
+}
+
 int svnicp_align_begin(svnicp_ctx* c) {
   CTX_CHECK(c);
   if (!c->clouds_set || !c->particles_set)
@@ -293,16 +333,15 @@ int svnicp_align_begin(svnicp_ctx* c) {
   const int I = c->prm.iterations, P = c->P;
   const int64_t B = c->B;
   c->S = knn_pool_size(c->K);
-  {
-    const char* force_v1 = getenv("SVNICP_KNN_V1");  // A/B switch for tests and profiling
-    c->use_scan = !(force_v1 && force_v1[0] == '1') && knn_scan_plan(c->Mp, c->K, &c->scan_Ms, &c->scan_rank, &c->scan_S2);
-  }
-  if (c->use_scan) {
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (ensure_target_layout(c)) return c->err.empty() ? SVNICP_ERR_HIP : SVNICP_ERR_HIP;
+  if (c->knn_variant != 0) {
+    if (c->knn_variant == 2) c->scan_S2 = 2048;  // deep global pool; the select phase tightens before it sorts
     HIPCHK(c, c->pool2.ensure((size_t)B * c->scan_S2));
     HIPCHK(c, c->fail_list.ensure((size_t)B));
     HIPCHK(c, c->fail_count.ensure(1));
-    HIPCHK(c, c->pool_d.ensure((size_t)kFallbackGrid * 256 * c->S));   // fallback rows only
-    HIPCHK(c, c->pool_i.ensure((size_t)kFallbackGrid * 256 * c->S));
+    HIPCHK(c, c->pool_d.ensure((size_t)kFallbackGrid * 4 * kFallbackQW * c->S));   // fallback rows only
+    HIPCHK(c, c->pool_i.ensure((size_t)kFallbackGrid * 4 * kFallbackQW * c->S));
   } else {
     HIPCHK(c, c->pool_d.ensure((size_t)B * c->S));
     HIPCHK(c, c->pool_i.ensure((size_t)B * c->S));
@@ -340,7 +379,6 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->trh.p, 0, ((size_t)I + 1) * 8, c->stream));
   }
   c->pused = 0;
-  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   const int ctl_init[4] = {0, I, 0, 0};  // stop flag, finish_iter (SVGDICP.cpp:42)
   HIPCHK(c, hipMemcpyAsync(c->ctl.p, ctl_init, sizeof ctl_init, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->history.p, 0, (size_t)(I > 0 ? I : 1) * 6 * P * sizeof(float), c->stream));  // SVGDICP.cpp:172-174
@@ -364,7 +402,25 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
   a.M = c->M; a.Mp = c->Mp; a.b_lo = b_lo; a.b_hi = b_hi; a.K = c->K; a.S = c->S;
   a.pool_d = c->pool_d.p; a.pool_i = c->pool_i.p; a.out_idx = c->cand_idx.p; a.out_d2 = c->cand_d2.p;
   HIPCHK(c, prof_begin(c, KC_KNN));
-  if (c->use_scan) {
+  if (c->knn_variant == 2) {
+    const int64_t n = b_hi - b_lo;
+    if (n > 0) {
+      HIPCHK(c, launch_morton_order(c->src.p, b_lo, n, 1, c->pose0, c->bbox.p, c->keys_a.p, c->keys_b.p, c->vals_a.p,
+                                    c->qorder.p + b_lo, c->sort_tmp.p, c->sort_tmp_bytes, c->stream));
+      KnnTilesArgs k{};
+      k.src = c->src.p; k.pose = c->pose0; k.qorder = c->qorder.p + b_lo;
+      k.tx = c->tx.p; k.ty = c->ty.p; k.tz = c->tz.p; k.txf = c->txf.p; k.tyf = c->tyf.p; k.tzf = c->tzf.p;
+      k.torig = c->torig.p; k.tile_box = c->tile_box.p; k.emax_bits = c->emax.p;
+      k.M = c->M; k.Mp = c->Mp; k.n_tiles = (int)(c->Mp / 512); k.b_lo = b_lo; k.b_hi = b_hi; k.K = c->K; k.S2 = c->scan_S2;
+      k.pool = c->pool2.p; k.out_idx = c->cand_idx.p; k.out_d2 = c->cand_d2.p;
+      k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p;
+      if (c->prm.record_trace) { HIPCHK(c, c->stat_n.ensure((size_t)c->B)); k.stat_n = c->stat_n.p; }
+      HIPCHK(c, hipMemsetAsync(c->fail_count.p, 0, sizeof(int), c->stream));
+      HIPCHK(c, launch_knn_tiles(k, c->stream));
+      a.qlist = c->fail_list.p; a.qlist_count = c->fail_count.p; a.list_grid = kFallbackGrid; a.list_qw = kFallbackQW;
+      HIPCHK(c, launch_knn_topk(a, c->stream));
+    }
+  } else if (c->use_scan) {
     KnnScanArgs k{};
     k.src = c->src.p; k.pose = c->pose0; k.tx = c->tx.p; k.ty = c->ty.p; k.tz = c->tz.p;
     k.txf = c->txf.p; k.tyf = c->tyf.p; k.tzf = c->tzf.p; k.torig = c->torig.p; k.emax_bits = c->emax.p;
@@ -374,7 +430,7 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
     HIPCHK(c, hipMemsetAsync(c->fail_count.p, 0, sizeof(int), c->stream));
     HIPCHK(c, launch_knn_scan(k, c->stream));
     // redo the (rare) queries whose seeded threshold was too tight: streaming kernel, list mode
-    a.qlist = c->fail_list.p; a.qlist_count = c->fail_count.p; a.list_grid = kFallbackGrid;
+    a.qlist = c->fail_list.p; a.qlist_count = c->fail_count.p; a.list_grid = kFallbackGrid; a.list_qw = kFallbackQW;
     HIPCHK(c, launch_knn_topk(a, c->stream));
   } else {
     HIPCHK(c, launch_knn_topk(a, c->stream));
@@ -388,7 +444,7 @@ int svnicp_build_candidate_table(svnicp_ctx* c) {
   if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_build_candidate_table: call svnicp_align_begin first");
   if (bind(c)) return SVNICP_ERR_HIP;
   HIPCHK(c, prof_begin(c, KC_TABLE));
-  HIPCHK(c, launch_build_table2(c->cand_idx.p, c->B, c->K, c->tgt.p, c->table.p, c->tablef.p, c->cmaxb.p, c->stream));
+  HIPCHK(c, launch_build_table2(c->cand_idx.p, c->B, c->K, c->tgt.p, c->M, c->table.p, c->tablef.p, c->cmaxb.p, c->stream));
   HIPCHK(c, prof_end(c));
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   c->have_candidates = true;
@@ -541,8 +597,15 @@ int svnicp_get_runtime(svnicp_ctx* c, double out3[3]) {
 int svnicp_get_knn_fallbacks(svnicp_ctx* c, int* out) {
   CTX_CHECK(c);
   if (!c->have_candidates) return fail(c, SVNICP_ERR_INVALID, "no candidates yet");
-  if (!c->use_scan) { *out = -1; return SVNICP_OK; }
+  if (c->knn_variant == 0) { *out = -1; return SVNICP_OK; }
   return fetch(c, out, c->fail_count.p, sizeof(int));
+}
+
+int svnicp_get_knn_survivors(svnicp_ctx* c, int32_t* outB) {
+  CTX_CHECK(c);
+  if (!c->have_candidates || c->knn_variant != 2 || !c->prm.record_trace || !c->stat_n.p)
+    return fail(c, SVNICP_ERR_INVALID, "svnicp_get_knn_survivors: needs record_trace and the pruned stage-A kernel");
+  return fetch(c, outB, c->stat_n.p, (size_t)c->B * 4);
 }
 
 int svnicp_get_ambiguous_steps(svnicp_ctx* c, int* out) {

@@ -19,7 +19,8 @@ struct KnnArgs {
   double* out_d2;      // [B][K]
   const int32_t* qlist;     // list mode (fallback of k_knn_scan): query indices, else nullptr
   const int* qlist_count;   // device scalar: number of entries of qlist
-  int list_grid;            // list mode: number of workgroups (pool rows = list_grid*256)
+  int list_grid;            // list mode: number of workgroups
+  int list_qw;              // list mode: queries per wave chunk (pool rows = list_grid*4*list_qw)
 };
 int knn_pool_size(int K);
 int64_t knn_padded_targets(int64_t M);
@@ -50,6 +51,38 @@ hipError_t launch_knn_topk(const KnnArgs& a, hipStream_t st);
 hipError_t launch_build_table(const int32_t* idx, int64_t n_entries, const double* tgt, double* table,
                               hipStream_t st);
 
+// ---------------- Stage A pruned variant (spatial_prep.hip, knn_tiles.hip) ----------------
+struct KnnTilesArgs {
+  const double* src;
+  Pose0 pose;
+  const int32_t* qorder;          // [b_hi-b_lo] original query rows in Morton order
+  const double *tx, *ty, *tz;     // Morton-ordered target SoA (f64), NaN padded to Mp
+  const float *txf, *tyf, *tzf;   // f32 copies
+  const int32_t* torig;
+  const float* tile_box;          // [6][n_tiles]: lo xyz, hi xyz (outward rounded)
+  const unsigned long long* emax_bits;
+  int64_t M, Mp;
+  int n_tiles;
+  int64_t b_lo, b_hi;
+  int K, S2;
+  int32_t* pool;                  // [B][S2]
+  int32_t* out_idx;
+  double* out_d2;
+  int32_t* fail_list;
+  int* fail_count;
+  int32_t* stat_n;                // optional [B]: survivors of the f32 filter per query (first pass)
+};
+bool knn_tiles_applicable(int64_t Mp, int K);
+hipError_t launch_knn_tiles(const KnnTilesArgs& a, hipStream_t st);
+size_t sort_temp_bytes(size_t n);
+hipError_t launch_bbox(const double* pts, int64_t n, unsigned long long* bbox, hipStream_t st);
+hipError_t launch_morton_order(const double* pts, int64_t i0, int64_t n, int transform, const Pose0& pose,
+                               const unsigned long long* bbox, unsigned int* keys_a, unsigned int* keys_b,
+                               int32_t* vals_a, int32_t* order, void* temp, size_t temp_bytes, hipStream_t st);
+hipError_t launch_targets_sorted(const double* tgt, int64_t M, int64_t Mp, const int32_t* order, double* tx, double* ty,
+                                 double* tz, float* txf, float* tyf, float* tzf, int32_t* torig, float* tile_box,
+                                 unsigned long long* emax_bits, hipStream_t st);
+
 // ---------------- Stage B (stein_iter.hip) ----------------
 struct AccumArgs {
   const double* src;    // [B][3]
@@ -72,8 +105,8 @@ struct AccumArgs {
 };
 struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32; int64_t n_tiles; size_t smem; };
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, bool f32);
-hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, double* table, float4* tablef,
-                               float* cmax, hipStream_t st);
+hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
+                               float4* tablef, float* cmax, hipStream_t st);
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles,
                                   double* sums, const int* ctl, hipStream_t st);

@@ -1,0 +1,403 @@
+// knn_tiles.hip — Stage A, pruned variant: exact top-K with spatially sorted target tiles.
+//
+// Same result contract as knn_topk.hip / knn_scan.hip (reference: SVGDICP::knn_source_cloud,
+// src/core/SVGDICP.cpp:201-215; CPU semantics src/core/knn/knn_cpu.cpp:35-67): the K smallest by
+// (f64 dist², original index), ascending, dist² = ((dx·dx)+dy·dy)+dz·dz unfused.  It is still a
+// brute-force search in the sense that every pair that COULD be among a query's K nearest is
+// evaluated; what changes is that whole 512-point target tiles are skipped when their bounding box
+// is provably farther than the query's threshold.
+//
+//  0. spatial_prep.hip sorted targets and queries along a Morton curve; a wave owns 64 consecutive
+//     (hence nearby) queries, a tile is 512 consecutive targets with an outward-rounded f32 box.
+//  1. seed   The wave picks the ≤16 tiles nearest to its query box and scans them keeping TWO
+//     running f32 minima per (query, lane).  The 128 values of a query belong to 128 distinct
+//     targets, so their K-th smallest (K ≤ 128), inflated by the f32 error bound, is a threshold τ
+//     with AT LEAST K targets inside — a guarantee, not an estimate.
+//  2. scan   Tiles whose box-to-box lower bound exceeds the wave's largest threshold are skipped
+//     (one vector test per 64 tiles); inside a kept tile, queries whose point-to-box bound exceeds
+//     their own threshold are skipped (one vector test per tile).  The surviving (query, tile)
+//     pairs run the f32 pre-filter loop of knn_scan.hip; survivors go to the wave queue / pools.
+//  3. select exact f64 d² of the pool; when a query has many survivors its threshold is first
+//     tightened from the survivors themselves (same two-minima guarantee); keep d² <= τ, bitonic
+//     sort by (d², original index), write the K best to the query's ORIGINAL row.  Pool overflow
+//     (thousands of duplicates) falls back to the streaming kernel, as in knn_scan.hip.
+//
+// All bounds are conservative: boxes are rounded outward, f32 lower bounds are shrunk by 1e-6
+// relative, thresholds are inflated by the error terms derived in knn_scan.hip.
+#include "kernels.hpp"
+
+namespace svnicp {
+
+namespace {
+
+constexpr int T = 8;
+constexpr int STEP = kWave * T;   // 512 slots per tile
+constexpr int QW = 64;
+constexpr int WAVES = 4;
+constexpr int QCAP = 1024;
+constexpr int SL = 512;            // LDS sort capacity of the select phase
+constexpr int NSQ = 4;            // seed tiles chosen per query (the wave scans the union)
+constexpr int MAX_TILES = 8192;   // bitmap capacity (M <= 4M points)
+constexpr int QB = 16;            // queries per seed batch (LDS: QB*64*2 floats)
+constexpr double kU = 5.9604644775390625e-08;  // 2^-24
+
+struct alignas(16) QF { float x, y, z, thr; };
+struct alignas(16) QD { double x, y, z, tau; };
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ bool ent_less(double da, int ia, double db, int ib) {
+  return (da < db) || (da == db && ia < ib);
+}
+__device__ void bitonic_sort(double* sd, int* si, int S, int lane) {
+  for (int k = 2; k <= S; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int e = lane; e < (S >> 1); e += kWave) {
+        const int a = ((e & ~(j - 1)) << 1) | (e & (j - 1)), b = a | j;
+        const bool up = (a & k) == 0;
+        const double da = sd[a], db = sd[b];
+        const int ia = si[a], ib = si[b];
+        if (ent_less(db, ib, da, ia) == up) { sd[a] = db; si[a] = ib; sd[b] = da; si[b] = ia; }
+      }
+      wave_sync();
+    }
+}
+__device__ void bitonic_sort128_f32(float* v, int lane) {  // 128 floats, one compare-exchange per lane per round
+  for (int k = 2; k <= 128; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int a = ((lane & ~(j - 1)) << 1) | (lane & (j - 1)), b = a | j;
+      const bool up = (a & k) == 0;
+      const float va = v[a], vb = v[b];
+      if ((vb < va) == up) { v[a] = vb; v[b] = va; }
+      wave_sync();
+    }
+}
+__device__ __forceinline__ float next_down(float f) {
+  if (f == 0.0f) return -1.401298464e-45f;
+  int b = __float_as_int(f); b += (f > 0.0f) ? -1 : 1; return __int_as_float(b);
+}
+__device__ __forceinline__ float next_up(float f) {
+  if (f == 0.0f) return 1.401298464e-45f;
+  int b = __float_as_int(f); b += (f > 0.0f) ? 1 : -1; return __int_as_float(b);
+}
+__device__ __forceinline__ float f32_floor(double v) { float f = (float)v; return ((double)f > v) ? next_down(f) : f; }
+__device__ __forceinline__ float f32_ceil(double v) { float f = (float)v; return ((double)f < v) ? next_up(f) : f; }
+__device__ __forceinline__ float f32_round_up(double v) {
+  float f = (float)v;
+  if ((double)f < v) f = __int_as_float(__float_as_int(f) + 1);  // v >= 0
+  return f;
+}
+// f32 pre-filter threshold for exact threshold tau (bound derived in knn_scan.hip)
+__device__ __forceinline__ float filter_threshold(double tau, double E) {
+  if (!(tau < __builtin_huge_val())) return __builtin_huge_valf();
+  const double r = sqrt(tau) * (1.0 + 1e-15) + 3.4641016151377553 * kU * E;
+  return f32_round_up((r * r) * (1.0 + 5.0 * kU + 1e-6));
+}
+// lower bound of the squared distance between two boxes (or a degenerate box = point), shrunk
+__device__ __forceinline__ float box_lb2(float alo0, float alo1, float alo2, float ahi0, float ahi1, float ahi2,
+                                         float blo0, float blo1, float blo2, float bhi0, float bhi1, float bhi2) {
+  const float g0 = __builtin_fmaxf(0.0f, __builtin_fmaxf(blo0 - ahi0, alo0 - bhi0));
+  const float g1 = __builtin_fmaxf(0.0f, __builtin_fmaxf(blo1 - ahi1, alo1 - bhi1));
+  const float g2 = __builtin_fmaxf(0.0f, __builtin_fmaxf(blo2 - ahi2, alo2 - bhi2));
+  return (g0 * g0 + g1 * g1 + g2 * g2) * 0.999999f;
+}
+
+__global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = a.K, S2 = a.S2, n_tiles = a.n_tiles;
+  constexpr size_t kScratch = 10240;  // >= QB*64*8 + 512 + 1024 (seed), QCAP*8 (queue), S2*12 (select, S2 <= 768)
+  constexpr size_t per_wave = sizeof(QD) * QW + sizeof(QF) * QW + 4 * sizeof(int) * QW + kScratch;
+  unsigned char* base = smem + per_wave * wave;
+  QD* qd = reinterpret_cast<QD*>(base);
+  QF* qf = reinterpret_cast<QF*>(base + sizeof(QD) * QW);
+  int* cnt = reinterpret_cast<int*>(base + (sizeof(QD) + sizeof(QF)) * QW);
+  int* qb = cnt + QW;                                   // original row of each query
+  float* thrb = reinterpret_cast<float*>(qb + QW);      // box-test threshold per query
+  int* spare = reinterpret_cast<int*>(thrb + QW);       // [QW] unused padding
+  unsigned char* scratch = reinterpret_cast<unsigned char*>(spare + QW);
+  float2* lm = reinterpret_cast<float2*>(scratch);                 // seed: [QB][64] two minima
+  float* sv = reinterpret_cast<float*>(scratch + sizeof(float2) * QB * kWave);  // seed: [128] sort buffer
+  unsigned int* tbits = reinterpret_cast<unsigned int*>(sv + 128);              // seed: tile bitmap [MAX_TILES/32]
+  int2* queue = reinterpret_cast<int2*>(scratch);                  // scan: [QCAP] {slot, q}
+  double* sd = reinterpret_cast<double*>(scratch);                 // select: [SL]
+  int* si = reinterpret_cast<int*>(scratch + sizeof(double) * (size_t)SL);
+
+  const int64_t q0 = a.b_lo + ((int64_t)blockIdx.x * WAVES + wave) * QW;
+  if (q0 >= a.b_hi) return;  // no block-level barriers in this kernel
+  const int nq = (a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW;
+  const double Et = __longlong_as_double((long long)*a.emax_bits);
+
+  // ---- 0. this wave's queries (curve order) and their common box ----
+  float wlo0, wlo1, wlo2, whi0, whi1, whi2;
+  {
+    const bool act = lane < nq;
+    const int64_t b = act ? (int64_t)a.qorder[q0 - a.b_lo + lane] : 0;
+    QD s; s.x = s.y = s.z = 0.0; s.tau = 0.0;
+    if (act) {
+      const double sx = a.src[3 * b], sy = a.src[3 * b + 1], sz = a.src[3 * b + 2];
+      const double* R = a.pose.R0;
+      s.x = (sx * R[0] + sy * R[1] + sz * R[2]) + a.pose.t0[0];   // SVGDICP.cpp:204
+      s.y = (sx * R[3] + sy * R[4] + sz * R[5]) + a.pose.t0[1];
+      s.z = (sx * R[6] + sy * R[7] + sz * R[8]) + a.pose.t0[2];
+    }
+    qd[lane] = s;
+    QF f; f.x = (float)s.x; f.y = (float)s.y; f.z = (float)s.z; f.thr = -1.0f;
+    qf[lane] = f;
+    cnt[lane] = 0; qb[lane] = (int)b; thrb[lane] = -1.0f;
+    const float inf = __builtin_huge_valf();
+    wlo0 = act ? f32_floor(s.x) : inf; wlo1 = act ? f32_floor(s.y) : inf; wlo2 = act ? f32_floor(s.z) : inf;
+    whi0 = act ? f32_ceil(s.x) : -inf; whi1 = act ? f32_ceil(s.y) : -inf; whi2 = act ? f32_ceil(s.z) : -inf;
+    for (int off = 32; off > 0; off >>= 1) {
+      wlo0 = __builtin_fminf(wlo0, __shfl_xor(wlo0, off, kWave)); whi0 = __builtin_fmaxf(whi0, __shfl_xor(whi0, off, kWave));
+      wlo1 = __builtin_fminf(wlo1, __shfl_xor(wlo1, off, kWave)); whi1 = __builtin_fmaxf(whi1, __shfl_xor(whi1, off, kWave));
+      wlo2 = __builtin_fminf(wlo2, __shfl_xor(wlo2, off, kWave)); whi2 = __builtin_fmaxf(whi2, __shfl_xor(whi2, off, kWave));
+    }
+  }
+  wave_sync();
+  const float* bx_lo0 = a.tile_box, *bx_lo1 = a.tile_box + n_tiles, *bx_lo2 = a.tile_box + 2 * (size_t)n_tiles;
+  const float* bx_hi0 = a.tile_box + 3 * (size_t)n_tiles, *bx_hi1 = a.tile_box + 4 * (size_t)n_tiles,
+             * bx_hi2 = a.tile_box + 5 * (size_t)n_tiles;
+
+  // ---- 1. seed: nearest tiles, two minima per (query, lane), K-th of 128 -> guaranteed threshold ----
+  {
+    // each query (lane) picks its own NSQ nearest tiles: point-to-box bound, ties (inside several
+    // boxes) broken toward the nearest box centre; the wave scans the union of all picks
+    const int nwords = (n_tiles + 31) >> 5;
+    for (int e = lane; e < nwords; e += kWave) tbits[e] = 0u;
+    wave_sync();
+    {
+      const float px = qf[lane].x, py = qf[lane].y, pz = qf[lane].z;
+      unsigned long long best[NSQ];
+#pragma unroll
+      for (int i = 0; i < NSQ; ++i) best[i] = ~0ull;
+      for (int tile = 0; tile < n_tiles; ++tile) {  // tile boxes are wave-uniform (scalar loads)
+        const float l0 = bx_lo0[tile], l1 = bx_lo1[tile], l2 = bx_lo2[tile], h0 = bx_hi0[tile], h1 = bx_hi1[tile], h2 = bx_hi2[tile];
+        const float lb = box_lb2(px, py, pz, px, py, pz, l0, l1, l2, h0, h1, h2);
+        const float c0 = px - 0.5f * (l0 + h0), c1 = py - 0.5f * (l1 + h1), c2 = pz - 0.5f * (l2 + h2);
+        const float score = lb + 1e-3f * (c0 * c0 + c1 * c1 + c2 * c2);
+        unsigned long long key = (score < __builtin_huge_valf()) ? (((unsigned long long)__float_as_uint(score) << 32) | (unsigned int)tile) : ~0ull;
+#pragma unroll
+        for (int i = 0; i < NSQ; ++i) {  // insertion into the sorted top-NSQ
+          const unsigned long long lo = key < best[i] ? key : best[i];
+          key = key < best[i] ? best[i] : key;
+          best[i] = lo;
+        }
+      }
+      if (lane < nq) {
+#pragma unroll
+        for (int i = 0; i < NSQ; ++i)
+          if (best[i] != ~0ull) { const unsigned int t = (unsigned int)(best[i] & 0xffffffffull); atomicOr(&tbits[t >> 5], 1u << (t & 31)); }
+      }
+    }
+    wave_sync();
+    for (int qb0 = 0; qb0 < nq; qb0 += QB) {
+      const int nb = (nq - qb0) < QB ? (nq - qb0) : QB;
+      for (int e = lane; e < QB * kWave; e += kWave) lm[e] = make_float2(__builtin_huge_valf(), __builtin_huge_valf());
+      wave_sync();
+      for (int wd = 0; wd < nwords; ++wd) {
+        unsigned int bits = __builtin_amdgcn_readfirstlane(tbits[wd]);
+        while (bits) {
+          const int tile = (wd << 5) + (int)__builtin_ctz(bits);
+          bits &= bits - 1;
+          const int64_t tb = (int64_t)tile * STEP;
+          float x[T], y[T], z[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t) { x[t] = a.txf[tb + t * kWave + lane]; y[t] = a.tyf[tb + t * kWave + lane]; z[t] = a.tzf[tb + t * kWave + lane]; }
+          for (int q = 0; q < nb; ++q) {
+            const float4 cur = *reinterpret_cast<const float4*>(&qf[qb0 + q]);
+            float2 m = lm[q * kWave + lane];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const float dx = cur.x - x[t], dy = cur.y - y[t], dz = cur.z - z[t];
+              float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+              d = __builtin_fminf(d, __builtin_huge_valf());     // NaN padding -> +inf
+              m.y = __builtin_amdgcn_fmed3f(m.x, m.y, d);        // second smallest
+              m.x = __builtin_fminf(m.x, d);
+            }
+            lm[q * kWave + lane] = m;
+          }
+        }
+      }
+      wave_sync();
+      for (int q = 0; q < nb; ++q) {
+        const float2 m = lm[q * kWave + lane];
+        sv[2 * lane] = m.x; sv[2 * lane + 1] = m.y;
+        wave_sync();
+        bitonic_sort128_f32(sv, lane);
+        if (lane == 0) {
+          const double tv = (double)sv[K - 1];  // K <= 128 witnesses with f32 distance <= tv
+          const int qq = qb0 + q;
+          const double E = fmax(Et, fmax(fabs(qd[qq].x), fmax(fabs(qd[qq].y), fabs(qd[qq].z))));
+          double tau = __builtin_huge_val();
+          if (tv < (double)__builtin_huge_valf()) {
+            const double r = sqrt(tv) * (1.0 + 1e-6) + 4.0 * kU * E;  // exact distance of every witness <= r
+            tau = (r * r) * (1.0 + 1e-12);
+          }
+          qd[qq].tau = tau;
+          const float thr = filter_threshold(tau, E);
+          qf[qq].thr = thr;
+          float tb = __builtin_huge_valf();
+          if (thr < __builtin_huge_valf()) {  // point-to-box test uses the rounded query: allow its rounding error
+            const double rb = sqrt((double)thr) + 2.0 * kU * E;
+            tb = f32_round_up((rb * rb) * (1.0 + 1e-6));
+          }
+          thrb[qq] = tb;
+        }
+        wave_sync();
+      }
+    }
+  }
+
+  // ---- 2. scan the tiles that can matter ----
+  int qcount = 0;
+  auto flush = [&]() {
+    wave_sync();
+    for (int e = lane; e < qcount; e += kWave) {
+      const int2 ent = queue[e];
+      const int pos = atomicAdd(&cnt[ent.y], 1);
+      if (pos < S2) a.pool[(q0 + ent.y) * (int64_t)S2 + pos] = ent.x;
+    }
+    qcount = 0;
+    wave_sync();
+  };
+  {
+    float tmax = thrb[lane];  // -1 for inactive lanes
+    for (int off = 32; off > 0; off >>= 1) tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, off, kWave));
+    const float myx = qf[lane].x, myy = qf[lane].y, myz = qf[lane].z, mytb = thrb[lane];
+    for (int t0 = 0; t0 < n_tiles; t0 += kWave) {
+      const int tl = t0 + lane;
+      bool need = false;
+      if (tl < n_tiles)
+        need = box_lb2(wlo0, wlo1, wlo2, whi0, whi1, whi2, bx_lo0[tl], bx_lo1[tl], bx_lo2[tl], bx_hi0[tl], bx_hi1[tl],
+                       bx_hi2[tl]) <= tmax;
+      unsigned long long tmask = __ballot(need);
+      while (tmask) {
+        const int tile = t0 + (int)__builtin_ctzll(tmask);
+        tmask &= tmask - 1;
+        const float l0 = bx_lo0[tile], l1 = bx_lo1[tile], l2 = bx_lo2[tile], h0 = bx_hi0[tile], h1 = bx_hi1[tile], h2 = bx_hi2[tile];
+        unsigned long long qmask = __ballot(lane < nq && box_lb2(myx, myy, myz, myx, myy, myz, l0, l1, l2, h0, h1, h2) <= mytb);
+        if (!qmask) continue;
+        const int64_t tb = (int64_t)tile * STEP;
+        float x[T], y[T], z[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) { x[t] = a.txf[tb + t * kWave + lane]; y[t] = a.tyf[tb + t * kWave + lane]; z[t] = a.tzf[tb + t * kWave + lane]; }
+        while (qmask) {
+          const int q = (int)__builtin_ctzll(qmask);
+          qmask &= qmask - 1;
+          const float4 cur = *reinterpret_cast<const float4*>(&qf[q]);
+          float d[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const float dx = cur.x - x[t], dy = cur.y - y[t], dz = cur.z - z[t];
+            d[t] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          }
+          float dm = __builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]);
+#pragma unroll
+          for (int t = 3; t + 1 < T; t += 2) dm = __builtin_fminf(__builtin_fminf(dm, d[t]), d[t + 1]);
+          if constexpr ((T - 3) % 2 == 1) dm = __builtin_fminf(dm, d[T - 1]);
+          if (__ballot(dm <= cur.w)) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const unsigned long long m = __ballot(d[t] <= cur.w);
+              if (m) {
+                const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                if ((m >> lane) & 1ull) queue[pos] = make_int2((int)(tb + t * kWave + lane), q);
+                qcount += __popcll(m);
+              }
+            }
+            qcount = __builtin_amdgcn_readfirstlane(qcount);
+            if (qcount > QCAP - STEP) flush();
+          }
+        }
+      }
+    }
+    flush();
+  }
+
+  // ---- 3. select: exact f64, keep d2 <= tau, sort by (d2, original index), write to the original row ----
+  for (int q = 0; q < nq; ++q) {
+    const int64_t b = qb[q];
+    const int n_first = __builtin_amdgcn_readfirstlane(cnt[q]);
+    const double qx = qd[q].x, qy = qd[q].y, qz = qd[q].z;
+    double tau = qd[q].tau;
+    if (a.stat_n && lane == 0) a.stat_n[b] = n_first;
+    const int n = n_first;
+    bool ok = n <= S2;
+    int m = 0;
+    if (ok) {
+      if (n > SL / 2) {
+        // Many survivors (the threshold was loose for this query): tighten it from the survivors
+        // themselves.  Two smallest exact distances per lane -> 128 values from distinct targets; their
+        // K-th smallest has K witnesses, so it is a valid (and much tighter) threshold.
+        double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
+        for (int e = lane; e < n; e += kWave) {
+          const int slot = a.pool[(q0 + q) * (int64_t)S2 + e];
+          const double dx = qx - a.tx[slot], dy = qy - a.ty[slot], dz = qz - a.tz[slot];
+          const double d = (dx * dx + dy * dy) + dz * dz;
+          m2 = d < m1 ? m1 : (d < m2 ? d : m2);
+          m1 = d < m1 ? d : m1;
+        }
+        sd[2 * lane] = m1; sd[2 * lane + 1] = m2; si[2 * lane] = 0; si[2 * lane + 1] = 0;
+        wave_sync();
+        bitonic_sort(sd, si, 128, lane);
+        const double t2 = sd[K - 1];
+        wave_sync();
+        tau = t2 < tau ? t2 : tau;
+      }
+      for (int e0 = 0; e0 < n; e0 += kWave) {
+        const int e = e0 + lane;
+        bool pass = false;
+        double d = 0.0;
+        int orig = 0;
+        if (e < n) {
+          const int slot = a.pool[(q0 + q) * (int64_t)S2 + e];
+          orig = a.torig[slot];
+          const double dx = qx - a.tx[slot], dy = qy - a.ty[slot], dz = qz - a.tz[slot];
+          d = (dx * dx + dy * dy) + dz * dz;  // knn_cpu.cpp:43-50 order, unfused
+          pass = d <= tau;
+        }
+        const unsigned long long pm = __ballot(pass);
+        const int pos = m + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+        if (pass && pos < SL) { sd[pos] = d; si[pos] = orig; }
+        m += __popcll(pm);
+      }
+      ok = m >= K && m <= SL;
+    }
+    if (!ok) {
+      if (lane == 0) { const int slot = atomicAdd(a.fail_count, 1); a.fail_list[slot] = (int32_t)b; }
+      wave_sync();
+      continue;
+    }
+    int S = 128;
+    while (S < m) S <<= 1;
+    for (int e = m + lane; e < S; e += kWave) { sd[e] = __builtin_huge_val(); si[e] = 0x7fffffff; }
+    wave_sync();
+    bitonic_sort(sd, si, S, lane);
+    for (int e = lane; e < K; e += kWave) { a.out_idx[b * K + e] = si[e]; a.out_d2[b * K + e] = sd[e]; }
+    wave_sync();
+  }
+}
+
+}  // namespace
+
+bool knn_tiles_applicable(int64_t Mp, int K) { return K <= 128 && Mp >= 16 * STEP && (Mp % STEP) == 0 && Mp / STEP <= MAX_TILES; }
+
+hipError_t launch_knn_tiles(const KnnTilesArgs& a, hipStream_t st) {
+  const int64_t nq = a.b_hi - a.b_lo;
+  if (nq <= 0) return hipSuccess;
+  const int64_t nb = (nq + (int64_t)QW * WAVES - 1) / ((int64_t)QW * WAVES);
+  const size_t per_wave = sizeof(QD) * QW + sizeof(QF) * QW + 4 * sizeof(int) * QW + 10240;
+  if (a.n_tiles > MAX_TILES) return hipErrorInvalidValue;
+  const size_t smem = per_wave * WAVES;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_tiles),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_knn_tiles, dim3((unsigned)nb), dim3(256), smem, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace svnicp

@@ -101,14 +101,15 @@ __global__ __launch_bounds__(256) void k_knn_topk(KnnArgs a) {
   // knn_scan.hip): queries qlist[0..*qlist_count), chunks strided over the fixed grid.
   const bool list_mode = a.qlist != nullptr;
   const int64_t n_queries = list_mode ? (int64_t)*a.qlist_count : (a.b_hi - a.b_lo);
-  const int64_t n_chunks = (n_queries + QW - 1) / QW;
+  const int cq = list_mode ? a.list_qw : QW;  // queries per chunk: few in list mode, so failed queries spread over many waves
+  const int64_t n_chunks = (n_queries + cq - 1) / cq;
   const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
   const int64_t total_waves = (int64_t)gridDim.x * WAVES;
 
   for (int64_t chunk = wave_global; chunk < n_chunks; chunk += total_waves) {  // no block-level barriers inside
-    const int64_t c0 = chunk * QW;
-    const int nq = (n_queries - c0) < QW ? (int)(n_queries - c0) : QW;
-    const int64_t pool_row0 = list_mode ? wave_global * QW : a.b_lo + c0;
+    const int64_t c0 = chunk * cq;
+    const int nq = (n_queries - c0) < cq ? (int)(n_queries - c0) : cq;
+    const int64_t pool_row0 = list_mode ? wave_global * cq : a.b_lo + c0;
     {  // load + transform this wave's queries: q = R0·s + t0 (SVGDICP.cpp:204)
       QSlot s;
       int64_t b = 0;

@@ -383,16 +383,19 @@ __global__ __launch_bounds__(NT) void k_stein_accumulate_f32(AccumArgs a) {
 // candidate table: f64 absolute coordinates (target_batch = index_select(target, sourceKNN_idx),
 // SVGDICP.cpp:191-193, ONE copy), float32 local coordinates + |c'|², and C_b.  One wave per row.
 __global__ __launch_bounds__(256) void k_build_table2(const int32_t* __restrict__ idx, int64_t B, int K,
-                                                      const double* __restrict__ tgt, double* __restrict__ table,
+                                                      const double* __restrict__ tgt, int64_t M, double* __restrict__ table,
                                                       float4* __restrict__ tablef, float* __restrict__ cmax) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
-  const int64_t i0 = idx[b * K];
+  // indices are clamped into [0, M): a corrupted candidate list must never become a wild gather
+  int64_t i0 = idx[b * K];
+  i0 = i0 < 0 ? 0 : (i0 >= M ? M - 1 : i0);
   const double a0 = tgt[3 * i0], a1 = tgt[3 * i0 + 1], a2 = tgt[3 * i0 + 2];
   float cm = 0.0f;
   for (int k = lane; k < K; k += kWave) {
-    const int64_t i = idx[b * K + k];
+    int64_t i = idx[b * K + k];
+    i = i < 0 ? 0 : (i >= M ? M - 1 : i);
     const double x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
     double* o = table + ((size_t)b * K + k) * 3;
     o[0] = x; o[1] = y; o[2] = z;
@@ -512,10 +515,10 @@ hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st)
   }
 }
 
-hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, double* table, float4* tablef,
-                               float* cmax, hipStream_t st) {
+hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
+                               float4* tablef, float* cmax, hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_build_table2, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, idx, B, K, tgt, table, tablef, cmax);
+  hipLaunchKernelGGL(k_build_table2, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, idx, B, K, tgt, M, table, tablef, cmax);
   return hipGetLastError();
 }
 

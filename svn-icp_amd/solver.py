@@ -245,6 +245,13 @@ class _SolverBase:
         self._check(self._L.svnicp_get_knn_fallbacks(self._h, C.byref(v)), "svnicp_get_knn_fallbacks")
         return int(v.value)
 
+    def get_knn_survivors(self) -> np.ndarray:
+        """Per source point: targets that survived the f32 pre-filter of the pruned stage-A kernel (record_trace)."""
+        out = np.zeros(self._B, np.int32)
+        self._check(self._L.svnicp_get_knn_survivors(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))),
+                    "svnicp_get_knn_survivors")
+        return out
+
     def get_ambiguous_steps(self) -> int:
         """Wave steps whose float32 nearest-of-K search had to be redone in float64 (-1: f64 kernel only)."""
         v = C.c_int(0)

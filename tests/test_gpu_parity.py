@@ -106,10 +106,12 @@ def test_hip_vs_oracle(hip, orc, P, B, M, K, I, full, es, thr, md, lr):
 
 
 # ------------------------------------------------------------------ stage A variants
-@pytest.mark.parametrize("B,M,K", [(700, 20000, 7), (300, 9000, 1), (1000, 16384, 150), (513, 8192, 100), (64, 40000, 33)])
-def test_stage_a_prefiltered_kernel_bit_exact(hip, orc, B, M, K):
-    """knn_scan.hip (f32 pre-filter + seeded threshold): indices and dist² bit-identical to the
-    oracle's f64 brute force; the streaming kernel (SVNICP_KNN_V1=1) gives the same bits."""
+@pytest.mark.parametrize("B,M,K", [(700, 20000, 7), (300, 9000, 1), (1000, 16384, 128), (513, 8192, 100), (64, 40000, 33),
+                                   (900, 12000, 150)])
+def test_stage_a_variants_bit_exact(hip, orc, B, M, K):
+    """The three stage-A kernels — streaming (knn_topk.hip, SVNICP_KNN=v1), seeded f32 pre-filter
+    (knn_scan.hip, v2) and Morton-tile pruning (knn_tiles.hip, default for K <= 128) — must all give
+    indices and dist² bit-identical to the oracle's f64 brute force."""
     import os
     src, tgt = hip.scans.random_clouds(B, M, seed=B + K, extent=40.0)
     src = src + np.array([100.0, -50.0, 3.0])      # large coordinates: the filter slack must cover them
@@ -117,19 +119,27 @@ def test_stage_a_prefiltered_kernel_bit_exact(hip, orc, B, M, K):
     init = np.zeros((6, 2)); init[0, 1] = 0.01
     cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
     oi, od = orc.knn_topk(src, tgt, K)
-    res = []
-    for v1 in ("0", "1"):
-        os.environ["SVNICP_KNN_V1"] = v1
+    fbs = {}
+    for variant in ("v1", "v2", "default"):
+        if variant != "default":
+            os.environ["SVNICP_KNN"] = variant
         try:
-            s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+            s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init)
+            s.set_initial_mean((hip.scans.rot_zyx(0.01, -0.02, 0.03), np.array([0.3, -0.2, 0.1])))
+            s.stein_align()
         finally:
-            os.environ.pop("SVNICP_KNN_V1", None)
-        fb = s.get_knn_fallbacks()
-        assert (fb == -1) == (v1 == "1")
-        assert np.array_equal(s.get_candidates().astype(np.int64), oi)
-        assert np.array_equal(s.get_candidate_dist2(), od)
-        res.append(fb)
-    assert 0 <= res[0] <= max(2, B // 100)          # the seed is good: (almost) nothing falls back
+            os.environ.pop("SVNICP_KNN", None)
+        fbs[variant] = s.get_knn_fallbacks()
+        q = orc.transform(src, hip.scans.rot_zyx(0.01, -0.02, 0.03), np.array([0.3, -0.2, 0.1]))
+        oi, od = orc.knn_topk(q, tgt, K)
+        assert np.array_equal(s.get_candidates().astype(np.int64), oi), variant
+        assert np.array_equal(s.get_candidate_dist2(), od), variant
+    assert fbs["v1"] == -1
+    assert 0 <= fbs["v2"] <= max(2, B // 100)       # the probabilistic seed is good: (almost) nothing falls back
+    if K > 128:
+        assert fbs["default"] == fbs["v2"]          # knn_tiles does not apply: the default is the v2 kernel
+    else:
+        assert 0 <= fbs["default"] <= max(2, B // 100)  # guaranteed seed + in-kernel overflow recovery
 
 
 def test_stage_a_fallback_on_pool_overflow(hip, orc):

@@ -146,11 +146,18 @@ def main():
     }
 
     if world == 1 and kernel_ms:
-        # algorithmic work per launch (DESIGN.md "Kernels"): 8 flop per f64 point-pair distance, unfused
+        # Algorithmic work per launch (SURVEY.md §8d per-unit figures): 8 unfused f64 flop
+        # per point-pair distance of the reference's brute force; bytes = clouds/candidates in + results out.
         work = {
-            "k_knn_topk": dict(bytes=24.0 * (B + M) + 12.0 * B * K, flops=8.0 * B * M),
+            "stage_a_knn": dict(bytes=24.0 * (B + M) + 12.0 * B * K, flops=8.0 * B * M),
             "k_stein_accumulate": dict(bytes=24.0 * B + 24.0 * B * K, flops=8.0 * P * B * K),
         }
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f).get(wl, {})
+        except OSError:
+            pass
         details = {}
         for k, (ms, n) in kernel_ms.items():
             d = {"launches_per_registration": n // a.steps, "avg_launch_ms": ms / max(n, 1),
@@ -164,13 +171,17 @@ def main():
         avg_s = kernel_ms[dom][0] / max(kernel_ms[dom][1], 1) * 1e-3
         ach = work[dom]["bytes"] / avg_s / 1e9
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "note": "brute-force NN is f64-VALU-bound, not HBM-bound: see roofline_valu"}
+                           "frac": ach / HBM_PEAK_GBS,
+                           "traffic": traffic.get(dom, {}).get("bytes") if P == 128 else None,
+                           "note": "nearest-neighbour search is VALU-bound, not HBM-bound (SURVEY.md §8d): see "
+                                   "roofline_valu; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch "
+                                   "(profiles/traffic.json)"}
         tf = work[dom]["flops"] / avg_s / 1e12
         out["roofline_valu"] = {"kernel": dom, "bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TF,
                                 "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TF,
-                                "note": "8 unfused flop per pair; peak counts FMA as 2 flop, so 0.5 is the ceiling "
-                                        "for mul/add-only code"}
+                                "note": "algorithmic flops of the reference's f64 brute force (8 per pair) per launch "
+                                        "time; the kernels reach them with exact float32 pre-filters / pruning, so "
+                                        "this is an effective rate, not an instruction count"}
         out["kernels"] = details
 
     if rank == 0 and world == 1 and a.cpu_sample > 0:

@@ -155,8 +155,8 @@ int svnicp_get_knn_survivors(svnicp_ctx *ctx, int32_t *outB);
 int svnicp_get_ambiguous_steps(svnicp_ctx *ctx, int *out);
 /* bench hook: when on, every kernel launch of an align is bracketed by hipEvents on the
  * context's stream; svnicp_get_kernel_ms then returns the summed milliseconds and launch counts
- * per kernel class {k_knn_topk, k_build_table, k_stein_accumulate, k_reduce_partials,
- * k_particle_update} of the LAST align. */
+ * per kernel class {stage A (ordering + k_knn_tiles/k_knn_scan + fallback), k_build_table2,
+ * k_stein_accumulate*, k_reduce_partials, k_particle_update} of the LAST align. */
 int svnicp_set_profile(svnicp_ctx *ctx, int on);
 int svnicp_get_kernel_ms(svnicp_ctx *ctx, double *ms5, int32_t *launches5);
 

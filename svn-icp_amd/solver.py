@@ -220,7 +220,7 @@ class _SolverBase:
     def get_gpu_ms(self) -> np.ndarray:
         return self._getd("gpu_ms", 3)
 
-    KERNEL_CLASSES = ("k_knn_topk", "k_build_table", "k_stein_accumulate", "k_reduce_partials", "k_particle_update")
+    KERNEL_CLASSES = ("stage_a_knn", "k_build_table", "k_stein_accumulate", "k_reduce_partials", "k_particle_update")
 
     def set_profile(self, on: bool):
         self._check(self._L.svnicp_set_profile(self._h, int(on)), "svnicp_set_profile")

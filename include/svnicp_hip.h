@@ -79,8 +79,11 @@ void svnicp_destroy(svnicp_ctx *ctx);
 const char *svnicp_last_error(const svnicp_ctx *ctx); /* ctx may be NULL: last create() error */
 int svnicp_abi_version(void);
 
-/* run on this hipStream_t instead of the context's own stream (0 = back to own stream);
- * lets a host that owns streams (torch, ROS executor) keep everything in one queue */
+/* run on this hipStream_t instead of the context's private stream: lets a host that owns streams
+ * (torch, a ROS executor) keep kernels, copies and collectives in ONE queue.  NULL is a valid
+ * handle — HIP's default (null) stream, which is what torch.cuda.current_stream() usually is;
+ * pass SVNICP_OWN_STREAM to return to the private stream. */
+#define SVNICP_OWN_STREAM ((void *)(intptr_t)-1)
 int svnicp_set_stream(svnicp_ctx *ctx, void *hip_stream);
 int svnicp_synchronize(svnicp_ctx *ctx);
 

@@ -199,7 +199,9 @@ void svnicp_destroy(svnicp_ctx* c) {
 
 int svnicp_set_stream(svnicp_ctx* c, void* hip_stream) {
   CTX_CHECK(c);
-  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // nothing of ours may still be in flight on the old stream
+  c->stream = hip_stream == SVNICP_OWN_STREAM ? c->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
   return SVNICP_OK;
 }
 

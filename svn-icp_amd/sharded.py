@@ -104,8 +104,16 @@ class HipBackend:
 
 
 def _all_gather_rows(dist, group, full, lo, hi, world, rank):
-    """In-place all-gather of row blocks of `full` ([n, w]); block r = rows shard_range(n, world, r)."""
+    """In-place all-gather of row blocks of `full` ([n, w]); block r = rows shard_range(n, world, r).
+    RCCL (backend "nccl") gathers straight into the library's device buffer.  With a host-only backend
+    (gloo: the CPU test, or a single-GPU rehearsal with several ranks on one card) device rows are staged
+    through host memory."""
     import torch
+    if full.device.type != "cpu" and dist.get_backend(group) != "nccl":
+        host = full.cpu()
+        _all_gather_rows(dist, group, host, lo, hi, world, rank)
+        full.copy_(host)
+        return
     n = full.shape[0]
     per = (n + world - 1) // world
     if n == per * world:

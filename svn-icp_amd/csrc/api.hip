@@ -53,6 +53,7 @@ struct svnicp_ctx {
   AccumPlan plan{};
   int plan_P = -1; int64_t plan_B = -1; int plan_K = -1;
 
+  DevBuf<double> eul, opt;
   DevBuf<double> src, tgt, tx, ty, tz, pool_d, cand_d2, table, init_pose, R, t, Rtot, pose_out, sums, partial, work,
       stats, trH, trb, trN, trphi, trh;
   DevBuf<int32_t> pool_i, cand_idx, trcorr, torig, pool2, fail_list;
@@ -189,6 +190,7 @@ void svnicp_destroy(svnicp_ctx* c) {
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
   for (auto* b : dbl) b->release();
+  c->eul.release(); c->opt.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
   c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -242,6 +244,8 @@ int svnicp_set_particles(svnicp_ctx* c, const double* init, int P) {
   HIPCHK(c, c->sums.ensure((size_t)P * kNSums));
   HIPCHK(c, c->stats.ensure((size_t)48 + P));
   HIPCHK(c, c->work.ensure(update_workspace_doubles(P)));
+  HIPCHK(c, c->eul.ensure((size_t)P * 6));
+  HIPCHK(c, c->opt.ensure((size_t)P * 18));
   HIPCHK(c, hipMemcpyAsync(c->init_pose.p, init, (size_t)P * 48, hipMemcpyHostToDevice, c->stream));
   const bool first = !c->particles_set || P != c->P;
   c->P = P;
@@ -249,7 +253,7 @@ int svnicp_set_particles(svnicp_ctx* c, const double* init, int P) {
   // ctor semantics: pose_particles_ is formed from the initial pose (SVNICP.cpp:36-37, SVGDICP.cpp:33-35);
   // add_cloud semantics: R_, t_ are reset, pose_particles_ is left alone (SVGDICP.cpp:46-62)
   HIPCHK(c, launch_init_particles(c->init_pose.p, P, c->pose0, c->prm.mode, c->R.p, c->t.p, c->Rtot.p, c->pose_out.p,
-                                  (first || c->prm.mode == SVNICP_MODE_SVN) ? 1 : 0, c->stream));
+                                  (first || c->prm.mode == SVNICP_MODE_SVN) ? 1 : 0, c->eul.p, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->particles_set = true;
   c->particles_dirty = true;
@@ -329,8 +333,6 @@ int svnicp_align_begin(svnicp_ctx* c) {
   CTX_CHECK(c);
   if (!c->clouds_set || !c->particles_set)
     return fail(c, SVNICP_ERR_INVALID, "svnicp_align: svnicp_set_clouds and svnicp_set_particles must come first");
-  if (c->prm.mode == SVNICP_MODE_SVGD)
-    return fail(c, SVNICP_ERR_INVALID, "svnicp_align: SVGD mode is not built yet in this round (SVN mode only)");
   if (bind(c)) return SVNICP_ERR_HIP;
   const int I = c->prm.iterations, P = c->P;
   const int64_t B = c->B;
@@ -386,7 +388,9 @@ int svnicp_align_begin(svnicp_ctx* c) {
   HIPCHK(c, hipMemsetAsync(c->history.p, 0, (size_t)(I > 0 ? I : 1) * 6 * P * sizeof(float), c->stream));  // SVGDICP.cpp:172-174
   // total pose of iteration 0 from the CURRENT R_, t_ and R0, t0 (SVNICP.cpp:58-59)
   HIPCHK(c, launch_init_particles(c->init_pose.p, P, c->pose0, 2, c->R.p, c->t.p, c->Rtot.p, c->pose_out.p, 0,
-                                  c->stream));
+                                  nullptr, c->stream));
+  if (c->prm.mode == SVNICP_MODE_SVGD)  // a fresh torch::optim optimizer per stein_align (SVGDICP.cpp:73,142-170)
+    HIPCHK(c, hipMemsetAsync(c->opt.p, 0, (size_t)P * 18 * sizeof(double), c->stream));
   c->particles_dirty = false;
   c->began = true;
   c->have_result = false;
@@ -466,6 +470,7 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K;
   a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
   a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;
+  a.svgd = c->prm.mode == SVNICP_MODE_SVGD ? 1 : 0;
   HIPCHK(c, prof_begin(c, KC_ACCUM));
   HIPCHK(c, launch_accumulate(c->plan, a, c->stream));
   HIPCHK(c, prof_end(c));
@@ -491,8 +496,10 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
     u.trH = c->trH.p + (size_t)it * c->P * 36; u.trb = c->trb.p + (size_t)it * c->P * 6;
     u.trN = c->trN.p + (size_t)it * c->P * 6; u.trphi = c->trphi.p + (size_t)it * c->P * 6; u.trh = c->trh.p + it;
   }
+  u.eul = c->eul.p; u.opt = c->opt.p; u.optimizer = c->prm.optimizer; u.n_src = (double)c->B;
   HIPCHK(c, prof_begin(c, KC_UPDATE));
-  HIPCHK(c, launch_update(u, c->stream));
+  if (c->prm.mode == SVNICP_MODE_SVGD) HIPCHK(c, launch_update_svgd(u, c->stream));
+  else HIPCHK(c, launch_update(u, c->stream));
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;
 }
@@ -523,6 +530,8 @@ void* svnicp_sums_devptr(svnicp_ctx* c) { return c ? (void*)c->sums.p : nullptr;
 
 int svnicp_align_async(svnicp_ctx* c) {
   CTX_CHECK(c);
+  if (c->prm.mode == SVNICP_MODE_SVGD && (c->prm.optimizer < 0 || c->prm.optimizer > 3))
+    return SVNICP_NO_OPTIMIZER;  // set_optimizer() found no optimizer: stein_align returns at once (SVGDICP.cpp:73-75)
   int rc = svnicp_align_begin(c);
   if (rc) return rc;
   if ((rc = svnicp_stage_candidates(c, 0, c->B))) return rc;
@@ -539,7 +548,7 @@ int svnicp_align(svnicp_ctx* c) {
   if (c->shard_set && (c->p_lo != 0 || c->p_hi != c->P))
     return fail(c, SVNICP_ERR_INVALID, "svnicp_align: a particle shard is set; drive the split-phase calls instead");
   int rc = svnicp_align_async(c);
-  if (rc) return rc;
+  if (rc) return rc;  // negative status, or SVNICP_NO_OPTIMIZER
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SVNICP_ALIGN_SUCCESS;
 }

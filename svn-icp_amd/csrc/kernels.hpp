@@ -102,6 +102,7 @@ struct AccumArgs {
   double* partial;      // [gridDim.x][Ppad][kNSums]
   const int* ctl;       // ctl[0] = stop flag
   int32_t* corr;        // optional trace [P][B] (this iteration), or nullptr
+  int svgd;             // SVGD-ICP mode: slot 4 of the sums counts non-zero rows (SVGDICP.cpp:404)
 };
 struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32; int64_t n_tiles; size_t smem; };
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, bool f32);
@@ -127,10 +128,16 @@ struct UpdateArgs {
   int* ctl;            // [0] stop flag, [1] finish_iter
   double *trH, *trb, *trN, *trphi, *trh;  // optional traces (per-iteration slices) or nullptr
   int h_in_lds;        // set by launch_update: per-particle H fits in LDS
+  // SVGD-ICP mode (k_particle_update_svgd)
+  double* eul;         // [P][6] optimizer parameters x,y,z,roll,pitch,yaw
+  double* opt;         // [3][P][6] optimizer state
+  int optimizer;       // SVNICP_OPT_*
+  double n_src;        // gradient_scaling_factor_ = B (SVGDICP.cpp:58)
 };
 size_t update_workspace_doubles(int P);
 hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose, int mode, double* R, double* t,
-                                 double* Rtot, double* pose_out, int refresh_pose, hipStream_t st);
+                                 double* Rtot, double* pose_out, int refresh_pose, double* eul, hipStream_t st);
+hipError_t launch_update_svgd(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
 struct StatsArgs { const double* pose; int P; int mode; double* out; /* mean6,var6,cov36,weightsP */ };
 hipError_t launch_stats(const StatsArgs& a, hipStream_t st);

@@ -61,11 +61,17 @@ __device__ void finalize_Hb(const double* s, const double* Rc, double* H, double
   b[5] = G[3] - G[1];
 }
 
-// threads cooperating on one particle in the Stein-direction phase (power of two, <= 64)
-__device__ __forceinline__ int threads_per_particle(int P) {
-  int tpp = 1;
-  while (tpp < 64 && tpp * 2 * P <= UT) tpp <<= 1;
-  return tpp;
+// shared state of the exact-median selection
+struct SelShared {
+  unsigned int hist[256];
+  unsigned long long prefix;
+  unsigned int rank;
+  int nan_flag;
+  double h;
+};
+__device__ __forceinline__ void sel_init(SelShared* S, int P, int tid) {
+  if (tid < 256) S->hist[tid] = 0;
+  if (tid == 0) { S->nan_flag = 0; S->prefix = 0ull; S->rank = (unsigned int)(((size_t)P * P - 1) / 2); S->h = __builtin_nan(""); }
 }
 
 __device__ __forceinline__ double pair_sq(const double* lx, int i, int j) {  // SVNICP.cpp:257-260
@@ -73,6 +79,90 @@ __device__ __forceinline__ double pair_sq(const double* lx, int i, int j) {  // 
 #pragma unroll
   for (int d = 0; d < 6; ++d) { const double df = lx[i * 6 + d] - lx[j * 6 + d]; s += df * df; }
   return s;
+}
+
+// h = median(all P² pair distances) / log(P+1)  (SVNICP.cpp:254-262 / SVGDICP.cpp:464-471): exact lower
+// median (torch::median) by an 8-pass radix select on the non-negative f64 bit patterns; keys stay in
+// registers when P² <= KREG*UT, two barriers per pass, the 256-bin scan runs in wave 0.  Block-wide call.
+__device__ void rbf_bandwidth(const double* lx, int P, double* sq_global, SelShared* S, int tid, int lane, int wave) {
+  const int n = P * P;
+  const bool keys_in_regs = n <= KREG * UT;
+  const float invP = 1.0f / (float)P;
+  unsigned long long key[KREG];
+  if (keys_in_regs) {
+#pragma unroll
+    for (int i = 0; i < KREG; ++i) {
+      const int e = i * UT + tid;
+      key[i] = ~0ull;
+      if (e < n) {
+        int r = (int)((float)e * invP);
+        if (r * P > e) --r;
+        if ((r + 1) * P <= e) ++r;
+        const double s = pair_sq(lx, r, e - r * P);
+        key[i] = (unsigned long long)__double_as_longlong(s);
+        if (s != s) S->nan_flag = 1;
+      }
+    }
+  } else {
+    for (int e = tid; e < n; e += UT) {
+      const int r = e / P;
+      const double s = pair_sq(lx, r, e - r * P);
+      sq_global[e] = s;
+      if (s != s) S->nan_flag = 1;
+    }
+    __syncthreads();
+  }
+  for (int pass = 7; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    const unsigned long long pre = S->prefix;
+    if (keys_in_regs) {
+#pragma unroll
+      for (int i = 0; i < KREG; ++i) {
+        const unsigned long long k = key[i];
+        if (i * UT + tid < n && (pass == 7 || (k >> (shift + 8)) == pre)) atomicAdd(&S->hist[(k >> shift) & 255ull], 1u);
+      }
+    } else {
+      for (int e = tid; e < n; e += UT) {
+        const unsigned long long k = (unsigned long long)__double_as_longlong(sq_global[e]);
+        if (pass == 7 || (k >> (shift + 8)) == pre) atomicAdd(&S->hist[(k >> shift) & 255ull], 1u);
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      unsigned int c[4], tot = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { c[i] = S->hist[4 * lane + i]; tot += c[i]; S->hist[4 * lane + i] = 0; }
+      unsigned int incl = tot;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned int v = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += v;
+      }
+      unsigned int cum = incl - tot;  // elements in bins before mine
+      const unsigned int rank = S->rank;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (rank >= cum && rank < cum + c[i]) {
+          S->prefix = (pre << 8) | (unsigned long long)(4 * lane + i);
+          S->rank = rank - cum;
+        }
+        cum += c[i];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double med = S->nan_flag ? __builtin_nan("") : __longlong_as_double((long long)S->prefix);
+    S->h = med / log((double)(P + 1));
+  }
+  __syncthreads();
+}
+
+// threads cooperating on one particle in the Stein-direction phase (power of two, <= 64)
+__device__ __forceinline__ int threads_per_particle(int P) {
+  int tpp = 1;
+  while (tpp < 64 && tpp * 2 * P <= UT) tpp <<= 1;
+  return tpp;
 }
 
 __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
@@ -88,11 +178,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
   double* lphi = lb + 6 * P;      // [P][6]  Stein direction
   const double* Hsrc = a.h_in_lds ? (lphi + 6 * P) : w.H;  // [P][36]
   double* lH = a.h_in_lds ? (lphi + 6 * P) : nullptr;
-  __shared__ unsigned int hist[256];
-  __shared__ unsigned long long sel_prefix;
-  __shared__ unsigned int sel_rank;
-  __shared__ int nan_flag;
-  __shared__ double sh_h;
+  __shared__ SelShared sel;
   __shared__ double sh_Hinv[36];
   __shared__ double sh_Hmean[36];
   __shared__ double sh_norm[UT / kWave];
@@ -123,38 +209,11 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { lx[p * 6 + i] = a.t[3 * p + i]; lx[p * 6 + 3 + i] = lg[i]; }
   }
-  if (tid < 256) hist[tid] = 0;
-  if (tid == 0) { nan_flag = 0; sel_prefix = 0ull; sel_rank = (unsigned int)(((size_t)P * P - 1) / 2); sh_h = __builtin_nan(""); }
+  sel_init(&sel, P, tid);
   __syncthreads();
 
   if (P > 1) {
-    // ---- 2. pairwise squared distances and mean Hessian (SVNICP.cpp:85) ----
-    const int n = P * P;
-    const bool keys_in_regs = n <= KREG * UT;
-    const float invP = 1.0f / (float)P;
-    unsigned long long key[KREG];
-    if (keys_in_regs) {
-#pragma unroll
-      for (int i = 0; i < KREG; ++i) {
-        const int e = i * UT + tid;
-        key[i] = ~0ull;
-        if (e < n) {
-          int r = (int)((float)e * invP);
-          if (r * P > e) --r;
-          if ((r + 1) * P <= e) ++r;
-          const double s = pair_sq(lx, r, e - r * P);
-          key[i] = (unsigned long long)__double_as_longlong(s);
-          if (s != s) nan_flag = 1;
-        }
-      }
-    } else {
-      for (int e = tid; e < n; e += UT) {
-        const int r = e / P;
-        const double s = pair_sq(lx, r, e - r * P);
-        w.sq[e] = s;
-        if (s != s) nan_flag = 1;
-      }
-    }
+    // ---- 2. mean Hessian (SVNICP.cpp:85) and its inverse, RBF bandwidth from the exact median ----
     if (!a.full_grad && tid < 36 * 8) {  // 8 lanes per entry, strided over particles, folded by shuffles
       const int e = tid >> 3, part = tid & 7;
       double s = 0.0;
@@ -176,53 +235,8 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
 #pragma unroll
       for (int r = 0; r < 6; ++r) sh_Hinv[6 * r + lane] = ok ? col[r] : __builtin_nan("");
     }
-    // ---- 3. exact lower median (torch::median, SVNICP.cpp:262): radix select on the non-negative
-    //         f64 bit patterns, 8 bits per pass; two barriers per pass, the 256-bin scan runs in wave 0 ----
-    for (int pass = 7; pass >= 0; --pass) {
-      const int shift = pass * 8;
-      const unsigned long long pre = sel_prefix;
-      if (keys_in_regs) {
-#pragma unroll
-        for (int i = 0; i < KREG; ++i) {
-          const unsigned long long k = key[i];
-          if (i * UT + tid < n && (pass == 7 || (k >> (shift + 8)) == pre)) atomicAdd(&hist[(k >> shift) & 255ull], 1u);
-        }
-      } else {
-        for (int e = tid; e < n; e += UT) {
-          const unsigned long long k = (unsigned long long)__double_as_longlong(w.sq[e]);
-          if (pass == 7 || (k >> (shift + 8)) == pre) atomicAdd(&hist[(k >> shift) & 255ull], 1u);
-        }
-      }
-      __syncthreads();
-      if (wave == 0) {
-        unsigned int c[4], tot = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { c[i] = hist[4 * lane + i]; tot += c[i]; hist[4 * lane + i] = 0; }
-        unsigned int incl = tot;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-          const unsigned int v = __shfl_up(incl, off, kWave);
-          if (lane >= off) incl += v;
-        }
-        unsigned int cum = incl - tot;  // elements in bins before mine
-        const unsigned int rank = sel_rank;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (rank >= cum && rank < cum + c[i]) {
-            sel_prefix = (pre << 8) | (unsigned long long)(4 * lane + i);
-            sel_rank = rank - cum;
-          }
-          cum += c[i];
-        }
-      }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      const double med = nan_flag ? __builtin_nan("") : __longlong_as_double((long long)sel_prefix);
-      sh_h = med / log((double)(P + 1));                      // SVNICP.cpp:262
-    }
-    __syncthreads();
-    const double h = sh_h;
+    rbf_bandwidth(lx, P, w.sq, &sel, tid, lane, wave);
+    const double h = sel.h;
     // ---- 4. Stein direction: TPP threads per particle split the sum over j, folded by shuffles;
     //         the pair distance is recomputed from LDS (bit-identical, cheaper than an HBM load) ----
     const int tpp = threads_per_particle(P);
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
   if (a.trH) {
     for (int e = tid; e < P * 36; e += UT) a.trH[e] = w.H[e];
     for (int e = tid; e < P * 6; e += UT) { a.trb[e] = lb[e]; a.trN[e] = lN[e]; a.trphi[e] = lphi[e]; }
-    if (tid == 0) *a.trh = sh_h;
+    if (tid == 0) *a.trh = sel.h;
   }
 
   // ---- 6. pose update (SVNICP.cpp:268-279) + early stop statistic ----
@@ -383,9 +397,180 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
   for (int e = tid; e < 6 * P; e += UT) a.history[(size_t)a.iteration * 6 * P + e] = (float)a.pose_out[e];
 }
 
+// ---------------------------------------------------------------------------------------------
+// SVGD-ICP mode (first-order sibling): replaces the tail of SVGDICP::stein_align per iteration
+// (src/core/SVGDICP.cpp:106-133): sgd_grad's finalisation (:398-455, Euler partials :335-396),
+// svgd_grad + rbf_kernel (:457-474), pose_update through torch::optim (:476-494, options :142-170),
+// the displacement early stop (:123-131) and the particle history (:133).
+// Reference quirk kept: the RBF kernel is evaluated on pose_particles_ as it stood BEFORE this
+// epoch's parameters were read, i.e. at epoch 0 on the previous registration's final particles.
+// ---------------------------------------------------------------------------------------------
+__device__ void euler_partials(const double* R0, double roll, double pitch, double yaw, double dR[3][9]) {
+  const double A = cos(yaw), Bs = sin(yaw), C = cos(pitch), D = sin(pitch), E = cos(roll), F = sin(roll);
+  const double DE = D * E, DF = D * F, AC = A * C, AF = A * F, AE = A * E;
+  const double ADE = A * DE, ADF = A * DF, BC = Bs * C, BE = Bs * E, BF = Bs * F, BDE = Bs * DE;
+  const double pr[9] = {0, ADE + BF, BE - ADF, 0, -AF + BDE, Bs * (-DF) - AE, 0, C * E, C * (-F)};
+  const double pp[9] = {A * -D, AC * F, AC * E, Bs * -D, BC * F, BC * E, -C, -DF, -DE};
+  const double py[9] = {-BC, -Bs * DF - AE, AF - BDE, AC, -BE + ADF, ADE + BF, 0, 0, 0};
+  mat3_mul(R0, pr, dR[0]);
+  mat3_mul(R0, pp, dR[1]);
+  mat3_mul(R0, py, dR[2]);
+}
+
+__global__ __launch_bounds__(UT) void k_particle_update_svgd(UpdateArgs a) {
+  if (a.ctl[0]) return;
+  extern __shared__ __align__(16) double dyn[];
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  const int P = a.P;
+  Work w(a.work, P);
+  double* lx = dyn;             // [P][6] pose_particles_ before this epoch's step
+  double* lg = lx + 6 * P;      // [P][6] sgd gradient
+  double* lphi = lg + 6 * P;    // [P][6] stein gradient
+  __shared__ SelShared sel;
+  __shared__ double sh_norm[UT / kWave];
+
+  // ---- 1. sgd_grad from the raw sums (SVGDICP.cpp:398-455) ----
+  for (int p = tid; p < P; p += UT) {
+    const double* s = a.sums + (size_t)p * kNSums;
+    const double* eu = a.eul + 6 * p;
+    double dR[3][9];
+    euler_partials(a.pose.R0, eu[3], eu[4], eu[5], dR);
+    const double cnt1 = s[4] + 1.0;  // nonzero_count + 1
+    const double* R0 = a.pose.R0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)      // error.sum(1).matmul(R0) / (count + 1)
+      lg[p * 6 + j] = ((s[10] * R0[j] + s[11] * R0[3 + j] + s[12] * R0[6 + j]) / cnt1) * a.n_src;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {    // Σ_b e·(dR_k s) = Σ_ij dR_k[i][j]·(Σ_b e_i s_j)
+      double v = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v += dR[k][3 * i + j] * s[13 + 3 * i + j];
+      lg[p * 6 + 3 + k] = (v / cnt1) * a.n_src;
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) lx[p * 6 + d] = a.pose_out[d * P + p];
+  }
+  sel_init(&sel, P, tid);
+  __syncthreads();
+
+  // ---- 2. svgd_grad (SVGDICP.cpp:457-474) ----
+  if (P > 1) {
+    rbf_bandwidth(lx, P, w.sq, &sel, tid, lane, wave);
+    const double h = sel.h;
+    const int tpp = threads_per_particle(P);
+    const int per_pass = UT / tpp;
+    for (int base = 0; base < P; base += per_pass) {
+      const int pi = base + tid / tpp, part = tid % tpp;
+      const bool act = pi < P;
+      double xi[6], gr[6] = {0, 0, 0, 0, 0, 0}, kg[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int d = 0; d < 6; ++d) xi[d] = act ? lx[pi * 6 + d] : 0.0;
+      if (act)
+        for (int j = part; j < P; j += tpp) {
+          double df[6], sq = 0.0;
+#pragma unroll
+          for (int d = 0; d < 6; ++d) { df[d] = xi[d] - lx[j * 6 + d]; sq += df[d] * df[d]; }
+          const double k = exp(-sq / h);
+#pragma unroll
+          for (int d = 0; d < 6; ++d) { gr[d] += df[d] * k; kg[d] += k * (-lg[j * 6 + d]); }
+        }
+      for (int off = tpp >> 1; off > 0; off >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) { gr[d] += __shfl_xor(gr[d], off, kWave); kg[d] += __shfl_xor(kg[d], off, kWave); }
+      }
+      if (act && part == 0) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) lphi[pi * 6 + d] = (kg[d] + 2 / h * gr[d]) / P;
+      }
+    }
+  } else {
+    if (tid == 0)
+      for (int d = 0; d < 6; ++d) lphi[d] = -lg[d];          // SVGDICP.cpp:112
+  }
+  __syncthreads();
+
+  if (a.trN) {  // traces (tests only): newton slot carries the sgd gradient
+    for (int e = tid; e < P * 6; e += UT) { a.trN[e] = lg[e]; a.trphi[e] = lphi[e]; }
+    if (tid == 0) *a.trh = sel.h;
+  }
+
+  // ---- 3. optimizer step (param.grad = -stein_grad, SVGDICP.cpp:476-494), pose refresh, early stop ----
+  const int step = a.iteration + 1;
+  double my_norm = 0.0;
+  for (int p = tid; p < P; p += UT) {
+    double n2 = 0.0, e6[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      const int i = p * 6 + d;
+      double g = -lphi[i];
+      double v = a.eul[i];
+      double* m1 = a.opt + i; double* m2 = a.opt + (size_t)6 * P + i; double* m3 = a.opt + (size_t)12 * P + i;
+      switch (a.optimizer) {
+        case 0: {  // Adam: betas (0.9, 0.999), eps 1e-8
+          const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+          const double e1 = b1 * (*m1) + (1 - b1) * g;
+          const double e2 = b2 * (*m2) + (1 - b2) * g * g;
+          *m1 = e1; *m2 = e2;
+          const double bc1 = 1 - pow(b1, (double)step), bc2 = 1 - pow(b2, (double)step);
+          v -= (a.lr / bc1) * (e1 / (sqrt(e2) / sqrt(bc2) + eps));
+        } break;
+        case 1: {  // RMSprop: alpha .99, eps 1e-8, weight_decay 1e-8, momentum .9
+          const double alpha = 0.99, eps = 1e-8, wd = 1e-8, mom = 0.9;
+          g = g + wd * v;
+          const double sq = alpha * (*m1) + (1 - alpha) * g * g;
+          const double buf = mom * (*m2) + g / (sqrt(sq) + eps);
+          *m1 = sq; *m2 = buf;
+          v -= a.lr * buf;
+        } break;
+        case 2: v -= a.lr * g; break;  // SGD
+        default: {  // Adagrad: eps 1e-10
+          const double ss = (*m3) + g * g;
+          *m3 = ss;
+          v -= a.lr * (g / (sqrt(ss) + 1e-10));
+        } break;
+      }
+      a.eul[i] = v;
+      e6[d] = v;
+      const double df = v - lx[i];
+      n2 += df * df;
+    }
+    my_norm += sqrt(n2);
+    // next epoch: R_ = Euler(rx,ry,rz), t_ = (x,y,z) (SVGDICP.cpp:88-91)
+    double Rm[9], Rt[9], tt[3];
+    euler_to_R(e6[3], e6[4], e6[5], Rm);
+    mat3_mul(a.pose.R0, Rm, Rt);
+    mat3_vec(a.pose.R0, e6, tt);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { a.R[9 * p + i] = Rm[i]; a.Rtot[12 * p + i] = Rt[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a.t[3 * p + i] = e6[i]; a.Rtot[12 * p + 9 + i] = a.pose.t0[i] + tt[i]; }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) a.pose_out[d * P + p] = e6[d];   // pose_particles_ (SVGDICP.cpp:118-121)
+  }
+  bool stop = false;
+  if (a.check_early_stop) {
+    for (int off = 32; off > 0; off >>= 1) my_norm += __shfl_xor(my_norm, off, kWave);
+    if (lane == 0) sh_norm[wave] = my_norm;
+    __syncthreads();
+    double m = 0.0;
+    for (int i = 0; i < UT / kWave; ++i) m += sh_norm[i];
+    m /= P;
+    stop = (float)m < (float)a.conv_thr;                          // float32 compare (type promotion)
+  }
+  if (stop) {
+    if (tid == 0) { a.ctl[0] = 1; a.ctl[1] = a.iteration + 1; }   // finish_iter_ = epoch + 1 (:128)
+    return;
+  }
+  __syncthreads();
+  for (int e = tid; e < 6 * P; e += UT) a.history[(size_t)a.iteration * 6 * P + e] = (float)a.pose_out[e];
+}
+
 // constructor / add_cloud: R = Exp(r), t, total pose (SVNICP.cpp:20-38, SVGDICP.cpp:46-62)
 __global__ void k_init_particles(const double* __restrict__ init, int P, Pose0 pose, int mode, double* R, double* t,
-                                 double* Rtot, double* pose_out, int refresh_pose) {
+                                 double* Rtot, double* pose_out, int refresh_pose, double* eul) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   double r[3] = {0, 0, 0}, tv[3], Rm[9];
@@ -396,6 +581,9 @@ __global__ void k_init_particles(const double* __restrict__ init, int P, Pose0 p
     r[0] = init[3 * P + p]; r[1] = init[4 * P + p]; r[2] = init[5 * P + p];
     tv[0] = init[p]; tv[1] = init[P + p]; tv[2] = init[2 * P + p];
     if (mode == 0) so3_exp(r, Rm, nullptr); else euler_to_R(r[0], r[1], r[2], Rm);
+    if (mode == 1 && eul) {  // SVGD: the optimizer parameters are the pose entries themselves (SVGDICP.cpp:46-53)
+      for (int i = 0; i < 3; ++i) { eul[6 * p + i] = tv[i]; eul[6 * p + 3 + i] = r[i]; }
+    }
   }
   double Rt[9], tt[3];
   mat3_mul(pose.R0, Rm, Rt);
@@ -446,9 +634,9 @@ __global__ void k_stats(StatsArgs a) {
 size_t update_workspace_doubles(int P) { return (size_t)P * (36 + 6 * 4) + (size_t)P * P + 64; }
 
 hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose, int mode, double* R, double* t,
-                                 double* Rtot, double* pose_out, int refresh_pose, hipStream_t st) {
+                                 double* Rtot, double* pose_out, int refresh_pose, double* eul, hipStream_t st) {
   hipLaunchKernelGGL(k_init_particles, dim3((P + 127) / 128), dim3(128), 0, st, init6xP, P, pose, mode, R, t, Rtot,
-                     pose_out, refresh_pose);
+                     pose_out, refresh_pose, eul);
   return hipGetLastError();
 }
 
@@ -465,6 +653,18 @@ hipError_t launch_update(const UpdateArgs& a_in, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_particle_update, dim3(1), dim3(UT), smem, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_update_svgd(const UpdateArgs& a, hipStream_t st) {
+  const size_t smem = (size_t)a.P * 18 * sizeof(double);
+  if (smem > 150 * 1024) return hipErrorInvalidValue;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_particle_update_svgd),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_particle_update_svgd, dim3(1), dim3(UT), smem, st, a);
   return hipGetLastError();
 }
 

@@ -121,7 +121,9 @@ __global__ __launch_bounds__(NT) void k_stein_accumulate(AccumArgs a) {
         const double w0 = w * m0, w1 = w * m1, w2 = w * m2;
         acc[0] += w;
         acc[1] += w0; acc[2] += w1; acc[3] += w2;
-        acc[4] = fma(w0, m0, acc[4]); acc[5] = fma(w0, m1, acc[5]); acc[6] = fma(w0, m2, acc[6]);
+        // SVGD mode needs count_nonzero(mask·Ts summed over xyz) (SVGDICP.cpp:404) instead of Σw·s_x²
+        acc[4] = a.svgd ? acc[4] + ((best < a.max_dist && ((T0 + T1) + T2) != 0.0) ? 1.0 : 0.0) : fma(w0, m0, acc[4]);
+        acc[5] = fma(w0, m1, acc[5]); acc[6] = fma(w0, m2, acc[6]);
         acc[7] = fma(w1, m1, acc[7]); acc[8] = fma(w1, m2, acc[8]); acc[9] = fma(w2, m2, acc[9]);
         acc[10] += e0; acc[11] += e1; acc[12] += e2;
         acc[13] = fma(e0, m0, acc[13]); acc[14] = fma(e0, m1, acc[14]); acc[15] = fma(e0, m2, acc[15]);
@@ -192,7 +194,7 @@ struct Pending {
   int pt;              // point index inside the tile (source point re-read from LDS)
 };
 
-__device__ __forceinline__ void accumulate_point(const Pending& pd, const double* spts, double max_dist, double* acc) {
+__device__ __forceinline__ void accumulate_point(const Pending& pd, const double* spts, double max_dist, int svgd, double* acc) {
   const double dx = pd.T0 - pd.q0, dy = pd.T1 - pd.q1, dz = pd.T2 - pd.q2;
   const double best = (dx * dx + dy * dy) + dz * dz;   // exact d² of the winner (knn_cpu.cpp:43-50 order)
   double w = 1.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
@@ -206,7 +208,9 @@ __device__ __forceinline__ void accumulate_point(const Pending& pd, const double
   const double w0 = w * n0, w1 = w * n1, w2 = w * n2;
   acc[0] += w;
   acc[1] += w0; acc[2] += w1; acc[3] += w2;
-  acc[4] = fma(w0, n0, acc[4]); acc[5] = fma(w0, n1, acc[5]); acc[6] = fma(w0, n2, acc[6]);
+  // SVGD mode needs count_nonzero(mask·Ts summed over xyz) (SVGDICP.cpp:404) instead of Σw·s_x²
+  acc[4] = svgd ? acc[4] + ((best < max_dist && ((pd.T0 + pd.T1) + pd.T2) != 0.0) ? 1.0 : 0.0) : fma(w0, n0, acc[4]);
+  acc[5] = fma(w0, n1, acc[5]); acc[6] = fma(w0, n2, acc[6]);
   acc[7] = fma(w1, n1, acc[7]); acc[8] = fma(w1, n2, acc[8]); acc[9] = fma(w2, n2, acc[9]);
   acc[10] += e0; acc[11] += e1; acc[12] += e2;
   acc[13] = fma(e0, n0, acc[13]); acc[14] = fma(e0, n1, acc[14]); acc[15] = fma(e0, n2, acc[15]);
@@ -344,11 +348,11 @@ __global__ __launch_bounds__(NT) void k_stein_accumulate_f32(AccumArgs a) {
       Pending cur;
       cur.T0 = T0; cur.T1 = T1; cur.T2 = T2; cur.pt = valid ? pt : -1;
       cur.q0 = drow[3 * kb]; cur.q1 = drow[3 * kb + 1]; cur.q2 = drow[3 * kb + 2];
-      if (have && pend.pt >= 0) accumulate_point(pend, spts, a.max_dist, acc);
+      if (have && pend.pt >= 0) accumulate_point(pend, spts, a.max_dist, a.svgd, acc);
       pend = cur;
       have = true;
     }
-    if (have && pend.pt >= 0) accumulate_point(pend, spts, a.max_dist, acc);  // drain before the tile is replaced
+    if (have && pend.pt >= 0) accumulate_point(pend, spts, a.max_dist, a.svgd, acc);  // drain before the tile is replaced
   }
 
 #pragma unroll

@@ -70,3 +70,33 @@ def test_scan_generator_is_deterministic(pkg):
     assert r.min() >= 1.0 - 1e-6 and r.max() <= 100.0 + 1e-4
     # first uniform of stream 0 is a fixed constant of the counter-based generator
     assert abs(pkg.scans.uniform01(0, 1)[0] - pkg.scans.uniform01(0, 3)[0]) == 0
+
+
+def _build_example(root):
+    exe = os.path.join(root, "svn-icp_amd", "host", "example_register")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-I",
+                           os.path.join(root, "svn-icp_amd", "host"),
+                           os.path.join(root, "svn-icp_amd", "host", "example_register.cpp"), "-L",
+                           os.path.join(root, "svn-icp_amd"), "-lsvnicp_hip", "-Wl,-rpath," + os.path.join(root, "svn-icp_amd"),
+                           "-o", exe])
+    return exe
+
+
+def test_cpp_shim_compiles_links_and_fails_loudly_without_gpu(pkg):
+    """svn-icp_amd/host/svnicp_hip_shim.hpp (C++ mirror of the reference classes) builds against the C ABI;
+    without a gfx950 device the example exits with the library's error, not with a CPU result."""
+    import torch
+    root = os.path.dirname(os.path.dirname(pkg.library_path()))
+    exe = _build_example(root)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (covered by the gpu-marked test)")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_shim_registers_on_gpu(pkg):
+    root = os.path.dirname(os.path.dirname(pkg.library_path()))
+    exe = _build_example(root)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

@@ -68,6 +68,61 @@ def test_hip_reproduces_golden(hip, orc, name):
     _compare(s, o, tro, g["init"].shape[1])
 
 
+# ------------------------------------------------------------------ SVGD-ICP mode (first-order sibling)
+def _hip_svgd(pkg, init, cfg, trace=True):
+    prm = pkg.SteinICPParam(iterations=cfg["iterations"], lr=cfg["lr"], max_dist=cfg["max_dist"],
+                            check_early_stop=cfg["check_early_stop"], convergence_threshold=cfg["convergence_threshold"],
+                            KNN_count=cfg["knn_count"], optimizer=cfg["optimizer"], record_trace=trace)
+    return pkg.SVGDICP(prm, init)
+
+
+@pytest.mark.parametrize("name", golden_cases("svgd"))
+def test_hip_svgd_reproduces_golden_and_oracle(hip, orc, name):
+    """SVGD-ICP (SVGDICP.cpp:66-140) with each torch optimizer: golden vectors + oracle."""
+    g = load_golden(name)
+    s = _hip_svgd(hip, g["init"], g["cfg"])
+    s.add_cloud(g["src"], g["tgt"], g["init"]); s.set_initial_mean((g["R0"], g["t0"]))
+    assert s.stein_align() == int(g["state"])
+    n = int(g["iters_run"])
+    assert np.array_equal(s.get_candidates(), g["cand_idx"])
+    tr = s.get_trace()
+    assert (tr["corr"][:n] != g["corr"]).mean() <= 1e-4
+    assert np.allclose(tr["newton"][:n], g["newton"], rtol=1e-9, atol=1e-9)      # sgd gradient
+    assert np.allclose(tr["phi"][:n], g["phi"], rtol=1e-9, atol=1e-9)
+    if g["init"].shape[1] > 1:
+        assert np.allclose(tr["h"][:n], g["h"], rtol=1e-10)
+    for got, want in ((s.get_transformation(), g["mean"]), (s.get_distribution(), g["var"]), (s.get_cov_matrix(), g["cov"]),
+                      (s.get_particles(), g["particles"])):
+        assert np.allclose(got, want, rtol=0, atol=TIGHT)
+    assert np.array_equal(s.get_particle_weight(), g["weights"])
+    assert np.allclose(s.get_particle_history(), g["history"], atol=1e-6)
+    o = oracle_from_golden(orc, g); o.stein_align()
+    assert int(s.get_runtime()[2]) == o.finish_iter()
+    assert np.allclose(s.get_particles(), o.get_particles(), rtol=0, atol=TIGHT)
+
+
+def test_hip_svgd_stale_pose_quirk_and_no_optimizer(hip, orc):
+    """Two registrations on one solver object: the RBF kernel of the second run's first epoch sees the
+    FIRST run's final particles (pose_particles_ is not reset by add_cloud, SVGDICP.cpp:46-62,110)."""
+    P, B, M = 9, 400, 1500
+    cfg = dict(iterations=5, lr=0.01, max_dist=1.0, check_early_stop=False, convergence_threshold=1e-5, knn_count=12,
+               optimizer="Adam")
+    init1 = hip.scans.make_particles(P, seed=3) * 0.3
+    init2 = hip.scans.make_particles(P, seed=4) * 0.3
+    s = _hip_svgd(hip, init1, cfg, trace=False)
+    o = orc.Solver(init1, mode=orc.MODE_SVGD, svn_full_grad=False, **cfg)
+    for seed, init in ((31, init1), (32, init2)):
+        src, tgt = hip.scans.random_clouds(B, M, seed=seed)
+        s.add_cloud(src, tgt, init); s.stein_align()
+        o.add_cloud(src, tgt, init); o.stein_align()
+        assert np.allclose(s.get_particles(), o.get_particles(), rtol=0, atol=TIGHT)
+        assert np.allclose(s.get_cov_matrix(), o.get_cov_matrix(), rtol=0, atol=TIGHT)
+    bad = hip.SVGDICP(hip.SteinICPParam(iterations=3, KNN_count=5, optimizer="LBFGS"), init1)
+    src, tgt = hip.scans.random_clouds(100, 300, seed=1)
+    bad.add_cloud(src, tgt, init1)
+    assert bad.stein_align() == hip.SteinICPState.NO_OPTIMIZER     # SVGDICP.cpp:73-75,166-169
+
+
 # ------------------------------------------------------------------ seeded cases vs the oracle
 CASES = [
     # P, B, M, K, I, full, early_stop, thr, max_dist, lr

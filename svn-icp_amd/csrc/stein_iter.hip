@@ -219,7 +219,7 @@ __device__ __forceinline__ void accumulate_point(const Pending& pd, const double
 }
 
 template <int PW, int WP>
-__global__ __launch_bounds__(NT) void k_stein_accumulate_f32(AccumArgs a) {
+__global__ __launch_bounds__(NT, 4) void k_stein_accumulate_f32(AccumArgs a) {
   if (a.ctl[0]) return;
   constexpr int BW = kWave / PW;
   constexpr int WB = 4 / WP;

@@ -59,7 +59,7 @@ template <int OP> int run(const char* name, int wps, float* d, float4* tab, int 
 }
 int main() {
   float* d; float4* tab; CHECK(hipMalloc(&d, 4 << 20)); CHECK(hipMalloc(&tab, 128 * 16)); CHECK(hipMemset(tab, 0, 128 * 16));
-  for (int w : {2, 3, 4}) {
+  for (int w : {4, 6, 8}) {
     run<0>("3fma+min", w, d, tab, 4); run<3>("3fma+med3+min", w, d, tab, 5);
     run<1>("3fma+cmp+cndmask+med3+min", w, d, tab, 7); run<2>("add+3fma+andor+umin/umax/umin", w, d, tab, 8);
   }

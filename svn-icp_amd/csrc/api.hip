@@ -53,7 +53,7 @@ struct svnicp_ctx {
   AccumPlan plan{};
   int plan_P = -1; int64_t plan_B = -1; int plan_K = -1;
 
-  DevBuf<double> eul, opt;
+  DevBuf<double> eul, opt, uctl;
   DevBuf<double> src, tgt, tx, ty, tz, pool_d, cand_d2, table, init_pose, R, t, Rtot, pose_out, sums, partial, work,
       stats, trH, trb, trN, trphi, trh;
   DevBuf<int32_t> pool_i, cand_idx, trcorr, torig, pool2, fail_list;
@@ -86,6 +86,15 @@ struct svnicp_ctx {
   size_t pused = 0;
 };
 
+constexpr int kFusedUpdateMaxP = 128;  // measured crossover (C3: equal, P=256: 4.5x); above this the Stein step runs as workgroup-parallel kernels
+static int fused_update_max_p() {         // A/B switch for tests and profiling: SVNICP_FUSED_UPDATE_MAXP=<P>
+  static const int v = [] {
+    const char* e = getenv("SVNICP_FUSED_UPDATE_MAXP");
+    const int x = e ? atoi(e) : kFusedUpdateMaxP;
+    return x < 1 ? 1 : (x > 700 ? 700 : x);  // P = 1 has no pair statistics; the fused kernel's LDS ends near P = 800
+  }();
+  return v;
+}
 constexpr int kFallbackGrid = 256;  // workgroups of the streaming kernel when it only redoes failed queries
 constexpr int kFallbackQW = 2;      // … two queries per wave, so a few hundred failures still run in parallel
 
@@ -190,7 +199,7 @@ void svnicp_destroy(svnicp_ctx* c) {
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
   for (auto* b : dbl) b->release();
-  c->eul.release(); c->opt.release();
+  c->eul.release(); c->opt.release(); c->uctl.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
   c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -246,6 +255,7 @@ int svnicp_set_particles(svnicp_ctx* c, const double* init, int P) {
   HIPCHK(c, c->work.ensure(update_workspace_doubles(P)));
   HIPCHK(c, c->eul.ensure((size_t)P * 6));
   HIPCHK(c, c->opt.ensure((size_t)P * 18));
+  HIPCHK(c, c->uctl.ensure(update_uctl_doubles(P)));
   HIPCHK(c, hipMemcpyAsync(c->init_pose.p, init, (size_t)P * 48, hipMemcpyHostToDevice, c->stream));
   const bool first = !c->particles_set || P != c->P;
   c->P = P;
@@ -498,7 +508,9 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
   }
   u.eul = c->eul.p; u.opt = c->opt.p; u.optimizer = c->prm.optimizer; u.n_src = (double)c->B;
   HIPCHK(c, prof_begin(c, KC_UPDATE));
+  u.uctl = c->uctl.p;
   if (c->prm.mode == SVNICP_MODE_SVGD) HIPCHK(c, launch_update_svgd(u, c->stream));
+  else if (c->P > fused_update_max_p()) HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream));
   else HIPCHK(c, launch_update(u, c->stream));
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;

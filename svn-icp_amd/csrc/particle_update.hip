@@ -398,6 +398,423 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Large particle sets (P > 256: several GPUs' shards, or C4 on one GPU): the same per-iteration
+// Stein step as k_particle_update, cut into workgroup-parallel kernels so that the O(P²) pair work
+// runs on the whole chip instead of one CU.  Same arithmetic per particle.  The exact lower median of
+// the P² pair distances comes from two parallel passes over the pairs: (1) a histogram of the f64 keys
+// in logarithmic bins (48 octaves from 2^-40, 256 mantissa steps each; everything outside lands in the
+// edge bins) locates the bin holding the median and the rank inside it; (2) the keys of that one bin
+// (~0.4 % of the pairs) are collected and an exact radix select runs on them.  Deterministic, no
+// sampling, exact for any input (a degenerate distribution only makes the last select longer).
+// uctl doubles: [2] h  [3..38] Hinv ; as u64: [40] nan flag [41] ticket [42] median bin [43] rank inside
+// the bin [44] collected count ; [64 .. 64+P) step norms ; then the global histogram (u32 x HB_NB).
+// ---------------------------------------------------------------------------------------------
+constexpr int UCTL_H = 2, UCTL_HINV = 3, UCTL_NAN = 40, UCTL_TICKET = 41, UCTL_BIN = 42, UCTL_RANK = 43, UCTL_CNT = 44,
+              UCTL_NORM = 64;
+constexpr int HB_OCT = 48, HB_NB = HB_OCT * 256, HB_EXP0 = 1023 - 40;
+constexpr int SEL_LDS_KEYS = 16384;
+
+__device__ __forceinline__ int key_bin(unsigned long long k) {
+  const long long kb = (long long)(k >> 44) - ((long long)HB_EXP0 << 8);
+  return kb < 0 ? 0 : (kb >= HB_NB ? HB_NB - 1 : (int)kb);
+}
+__device__ __forceinline__ unsigned int* upd_hist(double* uctl, int P) {
+  return reinterpret_cast<unsigned int*>(uctl + UCTL_NORM + ((P + 7) & ~7));
+}
+__device__ __forceinline__ double* upd_hpart(double* uctl, int P) {  // [ceil(P/128)][36] partial Hessian sums
+  return uctl + UCTL_NORM + ((P + 7) & ~7) + HB_NB / 2;
+}
+
+__global__ __launch_bounds__(128) void k_upd_prepare(UpdateArgs a) {
+  if (a.ctl[0]) return;
+  __shared__ double sh_H[128 * 37];
+  const int P = a.P;
+  Work w(a.work, P);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int* gh = upd_hist(a.uctl, P);
+  for (int e = p; e < HB_NB; e += gridDim.x * blockDim.x) gh[e] = 0u;
+  if (p == 0) {
+    unsigned long long* u = reinterpret_cast<unsigned long long*>(a.uctl);
+    u[UCTL_NAN] = 0ull; u[UCTL_TICKET] = 0ull; u[UCTL_CNT] = 0ull;
+  }
+  if (p < P) {
+    double Rc[9], H[36], b[6], LU[36], x6[6];
+    int piv[6];
+    mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
+    finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; sh_H[threadIdx.x * 37 + i] = H[i]; }
+    const bool ok = lu6(LU, piv);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x6[i] = b[i];
+    lu6_solve(LU, piv, x6);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { w.b[p * 6 + i] = b[i]; w.N[p * 6 + i] = ok ? x6[i] : __builtin_nan(""); }
+    double lg[3];
+    so3_log(a.R + 9 * p, lg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { w.x[p * 6 + i] = a.t[3 * p + i]; w.x[p * 6 + 3 + i] = lg[i]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 36) {  // this workgroup's Hessian sum, fixed order (mean Hessian, SVNICP.cpp:85)
+    const int cnt = min(128, P - (int)blockIdx.x * 128);
+    double sacc = 0.0;
+    for (int q = 0; q < cnt; ++q) sacc += sh_H[q * 37 + threadIdx.x];
+    upd_hpart(a.uctl, P)[blockIdx.x * 36 + threadIdx.x] = sacc;
+  }
+}
+
+// pass 1 over all pairs: log-binned histogram (LDS per workgroup, merged with global atomics); the
+// last workgroup to finish scans it for the bin of the lower median
+__global__ __launch_bounds__(256) void k_upd_hist(UpdateArgs a) {
+  if (a.ctl[0]) return;
+  extern __shared__ __align__(16) double dyn[];
+  __shared__ unsigned int sh_scan[256];
+  __shared__ int sh_last;
+  const int tid = threadIdx.x;
+  const int P = a.P;
+  Work w(a.work, P);
+  double* lx = dyn;
+  unsigned int* lh = reinterpret_cast<unsigned int*>(dyn + 6 * P);
+  for (int e = tid; e < 6 * P; e += 256) lx[e] = w.x[e];
+  for (int e = tid; e < HB_NB; e += 256) lh[e] = 0u;
+  __syncthreads();
+  unsigned long long* u = reinterpret_cast<unsigned long long*>(a.uctl);
+  unsigned int* gh = upd_hist(a.uctl, P);
+  const int n = P * P;
+  bool nan = false;
+  for (int e = blockIdx.x * 256 + tid; e < n; e += gridDim.x * 256) {
+    const int i = e / P, j = e - i * P;
+    const double s = pair_sq(lx, i, j);
+    if (s != s) nan = true;
+    atomicAdd(&lh[key_bin((unsigned long long)__double_as_longlong(s))], 1u);
+  }
+  if (nan) u[UCTL_NAN] = 1ull;
+  __syncthreads();
+  for (int e = tid; e < HB_NB; e += 256) {
+    const unsigned int c = lh[e];
+    if (c) atomicAdd(&gh[e], c);
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) sh_last = (atomicAdd(&u[UCTL_TICKET], 1ull) == (unsigned long long)(gridDim.x - 1));
+  __syncthreads();
+  if (!sh_last) return;
+  __threadfence();
+  constexpr int CH = HB_NB / 256;  // bins per thread, contiguous
+  for (int e = tid; e < HB_NB; e += 256) lh[e] = __hip_atomic_load(&gh[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  unsigned int c[CH], tot = 0;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) { c[i] = lh[tid * CH + i]; tot += c[i]; }
+  sh_scan[tid] = tot;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const unsigned int v = tid >= off ? sh_scan[tid - off] : 0u;
+    __syncthreads();
+    sh_scan[tid] += v;
+    __syncthreads();
+  }
+  unsigned int cum = sh_scan[tid] - tot;
+  const unsigned int rank = (unsigned int)((n - 1) / 2);
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    if (rank >= cum && rank < cum + c[i]) { u[UCTL_BIN] = (unsigned long long)(tid * CH + i); u[UCTL_RANK] = rank - cum; }
+    cum += c[i];
+  }
+}
+
+// pass 2 over all pairs: the keys of the median's bin go to work.sq (LDS staging, one global atomic per workgroup)
+__global__ __launch_bounds__(256) void k_upd_collect(UpdateArgs a) {
+  if (a.ctl[0]) return;
+  extern __shared__ __align__(16) double dyn[];
+  __shared__ unsigned int sh_cnt;
+  __shared__ unsigned long long sh_base;
+  const int tid = threadIdx.x;
+  const int P = a.P;
+  Work w(a.work, P);
+  double* lx = dyn;
+  double* lbuf = dyn + 6 * P;  // capacity: this workgroup's pair count
+  for (int e = tid; e < 6 * P; e += 256) lx[e] = w.x[e];
+  if (tid == 0) sh_cnt = 0u;
+  __syncthreads();
+  unsigned long long* u = reinterpret_cast<unsigned long long*>(a.uctl);
+  const int bstar = (int)u[UCTL_BIN];
+  const int n = P * P;
+  for (int e = blockIdx.x * 256 + tid; e < n; e += gridDim.x * 256) {
+    const int i = e / P, j = e - i * P;
+    const double s = pair_sq(lx, i, j);
+    if (key_bin((unsigned long long)__double_as_longlong(s)) == bstar) lbuf[atomicAdd(&sh_cnt, 1u)] = s;
+  }
+  __syncthreads();
+  const unsigned int cnt = sh_cnt;
+  if (cnt == 0) return;
+  if (tid == 0) sh_base = atomicAdd(&u[UCTL_CNT], (unsigned long long)cnt);
+  __syncthreads();
+  const unsigned long long base = sh_base;
+  for (unsigned int e = tid; e < cnt; e += 256) w.sq[base + e] = lbuf[e];
+}
+
+// generic block-wide exact rank selection over n non-negative f64 keys given by key_at(e); passes above
+// first_pass are skipped with their digits taken from prefix0 (keys known to share those bits)
+template <class F>
+__device__ unsigned long long block_select(F key_at, int n, unsigned int rank, int first_pass, unsigned long long prefix0,
+                                           SelShared* S, int tid, int lane, int wave) {
+  if (tid < 256) S->hist[tid] = 0;
+  if (tid == 0) { S->prefix = prefix0; S->rank = rank; }
+  __syncthreads();
+  for (int pass = first_pass; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    const unsigned long long pre = S->prefix;
+    for (int e = tid; e < n; e += UT) {
+      const unsigned long long k = key_at(e);
+      if (pass == 7 || (k >> (shift + 8)) == pre) atomicAdd(&S->hist[(k >> shift) & 255ull], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      unsigned int c[4], tot = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { c[i] = S->hist[4 * lane + i]; tot += c[i]; S->hist[4 * lane + i] = 0; }
+      unsigned int incl = tot;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned int v = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += v;
+      }
+      unsigned int cum = incl - tot;
+      const unsigned int r = S->rank;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (r >= cum && r < cum + c[i]) { S->prefix = (pre << 8) | (unsigned long long)(4 * lane + i); S->rank = r - cum; }
+        cum += c[i];
+      }
+    }
+    __syncthreads();
+  }
+  return S->prefix;
+}
+
+// exact median inside its bin -> h ; mean Hessian and its inverse (default branch)
+__global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
+  if (a.ctl[0]) return;
+  extern __shared__ __align__(16) double dyn[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = a.P;
+  Work w(a.work, P);
+  __shared__ SelShared sel;
+  __shared__ double sh_Hmean[36];
+  const unsigned long long* u = reinterpret_cast<const unsigned long long*>(a.uctl);
+  const int m = (int)u[UCTL_CNT];
+  const unsigned int r = (unsigned int)u[UCTL_RANK];
+  const int bstar = (int)u[UCTL_BIN];
+  // interior bins share the top 20 key bits: passes 7 and 6 are known
+  const bool interior = bstar > 0 && bstar < HB_NB - 1;
+  const unsigned long long top20 = (unsigned long long)bstar + ((unsigned long long)HB_EXP0 << 8);
+  const int first_pass = interior ? 5 : 7;
+  const unsigned long long prefix0 = interior ? (top20 >> 4) : 0ull;
+  unsigned long long kmed;
+  if (m <= SEL_LDS_KEYS) {
+    for (int e = tid; e < m; e += UT) dyn[e] = w.sq[e];
+    __syncthreads();
+    auto key_at = [&](int e) -> unsigned long long { return (unsigned long long)__double_as_longlong(dyn[e]); };
+    kmed = block_select(key_at, m, r, first_pass, prefix0, &sel, tid, lane, wave);
+  } else {  // degenerate distribution (most pairs in one bin): same select on the global buffer
+    auto key_at = [&](int e) -> unsigned long long { return (unsigned long long)__double_as_longlong(w.sq[e]); };
+    kmed = block_select(key_at, m, r, first_pass, prefix0, &sel, tid, lane, wave);
+  }
+  if (!a.full_grad && tid < 36) {
+    const double* hp = upd_hpart(a.uctl, P);
+    double s = 0.0;
+    for (int q = 0; q < (P + 127) / 128; ++q) s += hp[q * 36 + tid];
+    sh_Hmean[tid] = s / P;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double med = u[UCTL_NAN] ? __builtin_nan("") : __longlong_as_double((long long)kmed);
+    a.uctl[UCTL_H] = med / log((double)(P + 1));              // SVNICP.cpp:262
+  }
+  if (!a.full_grad && wave == 1 && lane < 6) {                // linalg::inv (SVNICP.cpp:225)
+    double LU[36], col[6];
+    int piv[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
+    const bool ok = lu6(LU, piv);
+#pragma unroll
+    for (int r2 = 0; r2 < 6; ++r2) col[r2] = (r2 == lane) ? 1.0 : 0.0;
+    lu6_solve(LU, piv, col);
+#pragma unroll
+    for (int r2 = 0; r2 < 6; ++r2) a.uctl[UCTL_HINV + 6 * r2 + lane] = ok ? col[r2] : __builtin_nan("");
+  }
+}
+
+// pose update of one particle (SVNICP.cpp:268-279); its step norm goes to uctl[UCTL_NORM + p]
+__device__ void upd_pose_one(const UpdateArgs& a, int p, const double* phi) {
+  const int P = a.P;
+  double dR[9], Jl[9], dt[3], Rn[9], Rdt[3], Ro[9];
+  so3_exp(phi + 3, dR, Jl);
+  mat3_vec(Jl, phi, dt);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Ro[i] = a.R[9 * p + i];
+  mat3_mul(Ro, dR, Rn);
+  mat3_vec(Rn, dt, Rdt);
+  double tn[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tn[i] = Rdt[i] + a.t[3 * p + i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a.R[9 * p + i] = Rn[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) a.t[3 * p + i] = tn[i];
+  double Rt[9], tt[3];
+  mat3_mul(a.pose.R0, Rn, Rt);
+  mat3_vec(a.pose.R0, tn, tt);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a.Rtot[12 * p + i] = Rt[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) a.Rtot[12 * p + 9 + i] = a.pose.t0[i] + tt[i];
+  double n2 = 0.0;
+#pragma unroll
+  for (int d = 0; d < 6; ++d) n2 += phi[d] * phi[d];
+  a.uctl[UCTL_NORM + p] = sqrt(n2);
+  double lg[3];
+  so3_log(Rn, lg);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { a.pose_out[i * P + p] = tn[i]; a.pose_out[(3 + i) * P + p] = lg[i]; }
+  if (!a.check_early_stop) {  // no stop decision pending: the history row (SVNICP.cpp:103-107) can go out now
+    float* hrow = a.history + (size_t)a.iteration * 6 * P;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { hrow[i * P + p] = (float)tn[i]; hrow[(3 + i) * P + p] = (float)lg[i]; }
+  }
+}
+
+// Stein direction (SVNICP.cpp:218-252), one wavefront per particle, then that particle's pose update.
+// x and the Newton steps of all particles are read from the prepare kernel's arrays (L2 resident); R/t
+// of particle pi are only touched by its own wavefront.
+__global__ __launch_bounds__(256) void k_upd_direction(UpdateArgs a) {
+  if (a.ctl[0]) return;
+  constexpr int TPP = kWave;
+  const int tid = threadIdx.x;
+  const int P = a.P;
+  Work w(a.work, P);
+  const int pi = blockIdx.x * (256 / TPP) + tid / TPP, part = tid % TPP;
+  if (pi >= P) return;  // whole wavefront
+  const double h = a.uctl[UCTL_H];
+  double xi[6], phi[6];
+#pragma unroll
+  for (int d = 0; d < 6; ++d) xi[d] = w.x[pi * 6 + d];
+  if (!a.full_grad) {
+    double g[6] = {0, 0, 0, 0, 0, 0}, kn[6] = {0, 0, 0, 0, 0, 0}, ks = 0.0;
+    for (int j = part; j < P; j += TPP) {
+      double df[6], sq = 0.0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { df[d] = xi[d] - w.x[j * 6 + d]; sq += df[d] * df[d]; }
+      const double k = exp(-sq / h);
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { g[d] += df[d] * k; kn[d] += k * (-w.N[j * 6 + d]); }
+      ks += k;
+    }
+    for (int off = TPP >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { g[d] += __shfl_xor(g[d], off, kWave); kn[d] += __shfl_xor(kn[d], off, kWave); }
+      ks += __shfl_xor(ks, off, kWave);
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) g[d] = 2 / h * g[d];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double hg = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) hg += a.uctl[UCTL_HINV + 6 * r + c] * g[c];
+      phi[r] = (kn[r] + hg) / ks;
+    }
+  } else {
+    double Hm[36], uu[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 36; ++e) Hm[e] = 0.0;
+    for (int j = part; j < P; j += TPP) {
+      double df[6], sq = 0.0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { df[d] = xi[d] - w.x[j * 6 + d]; sq += df[d] * df[d]; }
+      const double k = exp(-sq / h);
+      double g[6];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) g[d] = 2 / h * (df[d] * k);
+      const double k2 = k * k;
+      const double* Hj = w.H + (size_t)j * 36;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Hm[6 * r + c] += k2 * Hj[6 * r + c] + g[r] * g[c];
+        uu[r] += k * (-w.b[j * 6 + r]) + g[r];
+      }
+    }
+    for (int off = TPP >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int e = 0; e < 36; ++e) Hm[e] += __shfl_xor(Hm[e], off, kWave);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) uu[r] += __shfl_xor(uu[r], off, kWave);
+    }
+#pragma unroll
+    for (int e = 0; e < 36; ++e) Hm[e] /= P;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) uu[r] /= P;
+    int piv[6];
+    const bool ok = lu6(Hm, piv);
+    double out[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < 6; ++c) {
+      double col[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) col[r] = (r == c) ? 1.0 : 0.0;
+      lu6_solve(Hm, piv, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) out[r] += col[r] * uu[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) phi[r] = ok ? a.lr * out[r] : __builtin_nan("");
+  }
+  if (part == 0) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) w.phi[pi * 6 + r] = phi[r];
+    upd_pose_one(a, pi, phi);
+  }
+}
+
+// early-stop decision on a fixed-order sum (SVNICP.cpp:95-101), traces, history (SVNICP.cpp:103-107)
+__global__ __launch_bounds__(256) void k_upd_finish(UpdateArgs a) {
+  if (a.ctl[0]) return;
+  const int tid = threadIdx.x;
+  const int P = a.P;
+  Work w(a.work, P);
+  __shared__ double sh_part[256];
+  __shared__ int sh_stop;
+  if (a.trH) {
+    for (int e = tid; e < P * 36; e += 256) a.trH[e] = w.H[e];
+    for (int e = tid; e < P * 6; e += 256) { a.trb[e] = w.b[e]; a.trN[e] = w.N[e]; a.trphi[e] = w.phi[e]; }
+    if (tid == 0) *a.trh = a.uctl[UCTL_H];
+  }
+  if (a.check_early_stop) {
+    double s = 0.0;
+    for (int p = tid; p < P; p += 256) s += a.uctl[UCTL_NORM + p];
+    sh_part[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {  // fixed tree: every replica decides alike
+      if (tid < off) sh_part[tid] += sh_part[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const double m = sh_part[0] / P;
+      const int stop = (float)m < (float)a.conv_thr;
+      if (stop) { a.ctl[0] = 1; a.ctl[1] = a.iteration + 1; }
+      sh_stop = stop;
+    }
+    __syncthreads();
+    if (sh_stop) return;
+  } else {
+    return;  // history already written by k_upd_direction
+  }
+  for (int e = tid; e < 6 * P; e += 256) a.history[(size_t)a.iteration * 6 * P + e] = (float)a.pose_out[e];
+}
+
+// ---------------------------------------------------------------------------------------------
 // SVGD-ICP mode (first-order sibling): replaces the tail of SVGDICP::stein_align per iteration
 // (src/core/SVGDICP.cpp:106-133): sgd_grad's finalisation (:398-455, Euler partials :335-396),
 // svgd_grad + rbf_kernel (:457-474), pose_update through torch::optim (:476-494, options :142-170),
@@ -632,11 +1049,39 @@ __global__ void k_stats(StatsArgs a) {
 }  // namespace
 
 size_t update_workspace_doubles(int P) { return (size_t)P * (36 + 6 * 4) + (size_t)P * P + 64; }
+size_t update_uctl_doubles(int P) { return (size_t)UCTL_NORM + (size_t)((P + 7) & ~7) + (size_t)HB_NB / 2 + (size_t)36 * ((P + 127) / 128) + 8; }
 
 hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose, int mode, double* R, double* t,
                                  double* Rtot, double* pose_out, int refresh_pose, double* eul, hipStream_t st) {
   hipLaunchKernelGGL(k_init_particles, dim3((P + 127) / 128), dim3(128), 0, st, init6xP, P, pose, mode, R, t, Rtot,
                      pose_out, refresh_pose, eul);
+  return hipGetLastError();
+}
+
+hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st) {
+  const int P = a.P;
+  const size_t n = (size_t)P * P;
+  const size_t xs = (size_t)P * 6 * sizeof(double);
+  int nb = (int)((n + 1023) / 1024);
+  if (nb > num_cus) nb = num_cus;
+  if (nb < 1) nb = 1;
+  const size_t per_block = ((n + (size_t)nb * 256 - 1) / ((size_t)nb * 256)) * 256;  // pairs one workgroup visits (upper bound)
+  const size_t lds_hist = xs + (size_t)HB_NB * sizeof(unsigned int);
+  const size_t lds_coll = xs + per_block * sizeof(double);
+  const size_t lds_sel = (size_t)SEL_LDS_KEYS * sizeof(double);
+  if (lds_hist > 150 * 1024 || lds_coll > 150 * 1024) return hipErrorInvalidValue;  // P > ~2000 on a 256-CU part
+  {  // raise the dynamic-LDS cap (per device; a cheap host-side call)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_collect), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sel);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_upd_prepare, dim3((P + 127) / 128), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(k_upd_hist, dim3(nb), dim3(256), lds_hist, st, a);
+  hipLaunchKernelGGL(k_upd_collect, dim3(nb), dim3(256), lds_coll, st, a);
+  hipLaunchKernelGGL(k_upd_select, dim3(1), dim3(UT), lds_sel, st, a);
+  hipLaunchKernelGGL(k_upd_direction, dim3((P + 3) / 4), dim3(256), 0, st, a);
+  if (a.check_early_stop || a.trH) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@ CONFIGS = {  # BASELINE.json configs (P particles, B source points, M target poi
     "C3": dict(P=128, B=131072, M=262144, I=20),
     "C4": dict(P=512, B=131072, M=262144, I=20),
     "C5": dict(P=128, B=131072, M=2097152, I=20),
+    "P256": dict(P=256, B=131072, M=262144, I=20),
     "P1024": dict(P=1024, B=131072, M=262144, I=20),  # per-GPU view of an 8-GPU weak-scaling run (update kernel sees all particles)
 }
 # known displacement of the source scan from the first target pose (x,y,z m; roll,pitch,yaw deg)

@@ -137,8 +137,11 @@ CASES = [
     (5, 100, 40, 64, 3, False, False, 1e-5, 1.0, 1.0),       # M < K: padded candidates (idx 0)
     (64, 256, 500, 16, 6, True, False, 1e-5, 1.0, 0.5),
     (128, 2048, 8192, 100, 5, False, False, 1e-5, 1.0, 1.0), # two particle waves per workgroup
-    (130, 1000, 5000, 100, 4, True, False, 1e-5, 1.0, 1.0),  # particle count not a multiple of 64
-    (300, 700, 3000, 24, 3, False, False, 1e-5, 1.0, 1.0),   # two particle groups (grid.y = 2)
+    (130, 1000, 5000, 100, 4, True, False, 1e-5, 1.0, 1.0),  # particle count not a multiple of 64; smallest sizes on the workgroup-parallel Stein step (P > 128)
+    (300, 700, 3000, 24, 3, False, False, 1e-5, 1.0, 1.0),   # two particle groups; workgroup-parallel Stein step (P > 256)
+    (257, 300, 1000, 8, 3, True, False, 1e-5, 1.0, 0.5),     # workgroup-parallel step, full SVN branch
+    (600, 400, 2000, 16, 4, False, True, 5e-3, 1.0, 1.0),    # P = 600, early-stop compare on the ordered norm sum
+    (1030, 260, 900, 8, 2, False, False, 1e-5, 1.0, 1.0),    # P > 1024 (8-GPU weak-scaling particle count and beyond)
     (32, 4096, 8192, 100, 6, False, False, 1e-5, 1.0, 1.0),
     (16, 3000, 9000, 200, 4, False, False, 1e-5, 1.0, 1.0),  # K > 128: larger candidate pool
 ]

@@ -88,7 +88,8 @@ struct AccumArgs {
   const double* src;    // [B][3]
   const double* table;  // [B][K][3] candidate coordinates (f64, absolute)
   const float4* tablef; // [B][K] float32 local coordinates + |c'|² (fast variant)
-  const float* cmax;    // [B] max |c'| per source point (fast variant)
+  const float4* tablea; // [B][2][64] float32 local rows in MFMA A-operand order (stein_mfma.hip)
+  const float* cmax;    // [B] max |c'| per source point (fast variants)
   int* ambig_count;     // optional statistic: wave steps that took the exact path, or nullptr
   const double* Rtot;   // [P][12]: R_total row-major (9) + t_total (3)
   int64_t B;
@@ -104,8 +105,13 @@ struct AccumArgs {
   int32_t* corr;        // optional trace [P][B] (this iteration), or nullptr
   int svgd;             // SVGD-ICP mode: slot 4 of the sums counts non-zero rows (SVGDICP.cpp:404)
 };
-struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32; int64_t n_tiles; size_t smem; };
-AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, bool f32);
+struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K; int64_t n_tiles; size_t smem; };
+// f32: 0 = float64 baseline, 1 = float32 VALU search, 2 = float32 MFMA search (falls back to 1 when K > 128 or P <= 8)
+AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32);
+int mfma_occupancy_blocks(int PW, int WP, int K, size_t smem);
+hipError_t launch_accumulate_mfma(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);
+hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
+                               float4* tablea, float* cmax, hipStream_t st);
 hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
                                float4* tablef, float* cmax, hipStream_t st);
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st);

@@ -25,13 +25,14 @@
 // LDS with one address per lane group (broadcast), rows padded to an odd stride so that distinct
 // rows never share a bank.  Each lane keeps its 22 accumulators in VGPRs for the whole launch;
 // cross-lane/wave/block reduction happens once at the end, in a fixed order (deterministic).
+#include <cstdlib>
+
 #include "kernels.hpp"
+#include "stein_common.hpp"
 
 namespace svnicp {
 
 namespace {
-
-constexpr int NT = 256;
 
 template <int PW, int WP>
 __global__ __launch_bounds__(NT) void k_stein_accumulate(AccumArgs a) {
@@ -180,44 +181,6 @@ __global__ __launch_bounds__(NT) void k_stein_accumulate(AccumArgs a) {
 // The winner's d², mask, weight and the 22 sums are computed in f64 exactly as in the baseline
 // kernel, so correspondences and sums are bit-identical to it.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rdlane_f64(double v, int l) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// one (particle, source point) result waiting for its winner's f64 coordinates
-struct Pending {
-  double T0, T1, T2;   // transformed source point
-  double q0, q1, q2;   // winner candidate (f64), loaded one search-loop ago
-  int pt;              // point index inside the tile (source point re-read from LDS)
-};
-
-__device__ __forceinline__ void accumulate_point(const Pending& pd, const double* spts, double max_dist, int svgd, double* acc) {
-  const double dx = pd.T0 - pd.q0, dy = pd.T1 - pd.q1, dz = pd.T2 - pd.q2;
-  const double best = (dx * dx + dy * dy) + dz * dz;   // exact d² of the winner (knn_cpu.cpp:43-50 order)
-  double w = 1.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
-  if (best < max_dist) {  // point_filter, SVGDICP.cpp:331-333
-    const double n = sqrt(best);                        // SVNICP.cpp:120
-    const double wq = max_dist / (max_dist + 3 * n);
-    w = wq * wq;                                        // SVNICP.cpp:122
-    e0 = w * dx; e1 = w * dy; e2 = w * dz;              // SVNICP.cpp:119,123
-    n0 = spts[3 * pd.pt]; n1 = spts[3 * pd.pt + 1]; n2 = spts[3 * pd.pt + 2];
-  }
-  const double w0 = w * n0, w1 = w * n1, w2 = w * n2;
-  acc[0] += w;
-  acc[1] += w0; acc[2] += w1; acc[3] += w2;
-  // SVGD mode needs count_nonzero(mask·Ts summed over xyz) (SVGDICP.cpp:404) instead of Σw·s_x²
-  acc[4] = svgd ? acc[4] + ((best < max_dist && ((pd.T0 + pd.T1) + pd.T2) != 0.0) ? 1.0 : 0.0) : fma(w0, n0, acc[4]);
-  acc[5] = fma(w0, n1, acc[5]); acc[6] = fma(w0, n2, acc[6]);
-  acc[7] = fma(w1, n1, acc[7]); acc[8] = fma(w1, n2, acc[8]); acc[9] = fma(w2, n2, acc[9]);
-  acc[10] += e0; acc[11] += e1; acc[12] += e2;
-  acc[13] = fma(e0, n0, acc[13]); acc[14] = fma(e0, n1, acc[14]); acc[15] = fma(e0, n2, acc[15]);
-  acc[16] = fma(e1, n0, acc[16]); acc[17] = fma(e1, n1, acc[17]); acc[18] = fma(e1, n2, acc[18]);
-  acc[19] = fma(e2, n0, acc[19]); acc[20] = fma(e2, n1, acc[20]); acc[21] = fma(e2, n2, acc[21]);
-}
-
 template <int PW, int WP>
 __global__ __launch_bounds__(NT, 4) void k_stein_accumulate_f32(AccumArgs a) {
   if (a.ctl[0]) return;
@@ -460,6 +423,7 @@ static int occ_t(const AccumPlan& pl) {
   return n > 8 ? 8 : n;
 }
 static int occupancy_blocks(const AccumPlan& pl) {
+  if (pl.f32 == 2) return mfma_occupancy_blocks(pl.PW, pl.WP, pl.K, pl.smem);
   switch (pl.PW) {
     case 8: return occ_t<8, 1>(pl);
     case 16: return occ_t<16, 1>(pl);
@@ -468,14 +432,15 @@ static int occupancy_blocks(const AccumPlan& pl) {
   }
 }
 
-AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, bool f32) {
+AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32) {
   AccumPlan pl{};
-  pl.f32 = f32 ? 1 : 0;
-  int PW = 8;
+  if (f32 == 2 && (K > 128 || n_particles <= 8)) f32 = 1;  // MFMA tiles: 16 particles wide, 128 candidate rows
+  pl.f32 = f32;
+  int PW = f32 == 2 ? 16 : 8;
   while (PW < 64 && PW < n_particles) PW <<= 1;
   int WP = 1;
   if (PW == 64) { WP = (n_particles + 63) / 64; if (WP >= 3) WP = 4; }
-  pl.PW = PW; pl.WP = WP;
+  pl.PW = PW; pl.WP = WP; pl.K = K;
   const int per_wg = PW * WP;
   pl.grid_y = (n_particles + per_wg - 1) / per_wg;
   pl.Ppad = pl.grid_y * per_wg;
@@ -483,17 +448,26 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, bool f
   const int pass = BW * WB;                  // points per workgroup pass
   pl.RS = (3 * K) | 1;
   // bytes per staged source point: baseline = padded f64 row + point; f32 variant = K float4 + point + anchor + C_b
-  const size_t per_pt = f32 ? ((size_t)((K + 3) & ~3) * 16 + 24 + 24 + 4) : ((size_t)(pl.RS + 3) * 8);
+  const size_t per_pt = f32 == 2 ? (size_t)(2048 + 24 + 24 + 4)
+                       : f32 ? ((size_t)((K + 3) & ~3) * 16 + 24 + 24 + 4) : ((size_t)(pl.RS + 3) * 8);
   int TP = pass;
   while (TP < 16) TP += pass;                // at least 16 points per tile …
-  while (TP > pass && (size_t)TP * per_pt > (f32 ? 32u : 60u) * 1024) TP -= pass;  // … within a modest LDS footprint
+  while (TP > pass && (size_t)TP * per_pt > (f32 == 2 ? 36u : f32 ? 32u : 60u) * 1024) TP -= pass;  // … within a modest LDS footprint
+  if (const char* e = getenv("SVNICP_TP")) {  // profiling knob: source points per LDS tile (rounded to whole passes)
+    const int t = atoi(e);
+    if (t >= pass && (size_t)t * per_pt <= 140u * 1024) TP = t / pass * pass;
+  }
   pl.TP = TP;
-  const size_t tile_bytes = (size_t)TP * per_pt + 4 * 16 + 16;
+  const size_t tile_bytes = (size_t)TP * per_pt + 4 * 16 + 16 + (f32 == 2 ? 4 * 64 * 20 + 16 : 0);  // + per-wave operand scratch
   const size_t red_bytes = (size_t)(WB - 1) * per_wg * kNSums * sizeof(double);
   pl.smem = tile_bytes > red_bytes ? tile_bytes : red_bytes;
   pl.n_tiles = (B + TP - 1) / TP;
   // one resident round of workgroups: a second, partial round would leave most of the chip idle
-  const int wg_per_cu = occupancy_blocks(pl);
+  int wg_per_cu = occupancy_blocks(pl);
+  if (const char* e = getenv("SVNICP_WGPCU")) {  // profiling knob: workgroups per CU the grid is sized for
+    const int t = atoi(e);
+    if (t >= 1 && t <= 8) wg_per_cu = t;
+  }
   int64_t want = (int64_t)num_cus * wg_per_cu / (pl.grid_y > 0 ? pl.grid_y : 1);
   if (want < 1) want = 1;
   int64_t gx = pl.n_tiles < want ? pl.n_tiles : want;
@@ -508,6 +482,7 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, bool f
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st) {
   a.TP = plan.TP; a.RS = plan.RS; a.tiles_per_block = plan.tiles_per_block; a.n_tiles = plan.n_tiles;
   a.Ppad = plan.Ppad;
+  if (plan.f32 == 2) return launch_accumulate_mfma(plan, a, st);
   switch (plan.PW) {
     case 8: return launch_t<8, 1>(plan, a, st);
     case 16: return launch_t<16, 1>(plan, a, st);

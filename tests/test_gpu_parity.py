@@ -218,27 +218,32 @@ def test_stage_a_fallback_on_pool_overflow(hip, orc):
     assert np.array_equal(s.get_candidate_dist2(), od)
 
 
-def test_stage_b_f32_search_is_bit_identical_to_f64_kernel(hip):
-    """stein_iter.hip: the float32-search kernel must reproduce the float64 baseline kernel
-    (SVNICP_ACCUM_V1=1) bit for bit — same correspondences, same sums, same particles."""
+@pytest.mark.parametrize("P,full,K", [(70, False, 60), (20, True, 60), (128, False, 100), (9, False, 128), (40, False, 17),
+                                      (33, False, 1)])
+def test_stage_b_f32_search_is_bit_identical_to_f64_kernel(hip, P, full, K):
+    """stein_iter.hip / stein_mfma.hip: the float32 searches (VALU: SVNICP_ACCUM=valu, matrix cores: default)
+    must reproduce the float64 baseline kernel (SVNICP_ACCUM=f64) bit for bit — same correspondences,
+    same sums, same particles."""
     import os
     src, tgt = hip.scans.random_clouds(6000, 20000, seed=77, extent=30.0)
     src = src + np.array([80.0, -40.0, 2.0]); tgt = tgt + np.array([80.0, -40.0, 2.0])
-    for P, full in ((70, False), (20, True)):
-        init = hip.scans.make_particles(P, seed=P) * 0.5
-        cfg = dict(iterations=6, lr=1.0, max_dist=1.0, knn_count=60, svn_full_grad=full)
-        out = []
-        for v1 in ("1", "0"):
-            os.environ["SVNICP_ACCUM_V1"] = v1
-            try:
-                s = _hip_solver(hip, init, trace=True, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
-            finally:
-                os.environ.pop("SVNICP_ACCUM_V1", None)
-            out.append((s.get_particles(), s.get_trace()["corr"], s.get_trace()["H"], s.get_ambiguous_steps()))
-        assert out[0][3] == -1 and out[1][3] >= 0
-        assert np.array_equal(out[0][1], out[1][1])
-        assert np.array_equal(out[0][2], out[1][2])
-        assert np.array_equal(out[0][0], out[1][0])
+    init = hip.scans.make_particles(P, seed=P) * 0.5
+    cfg = dict(iterations=6, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=full)
+    out = {}
+    for mode in ("f64", "valu", "mfma"):
+        os.environ["SVNICP_ACCUM"] = mode
+        try:
+            s = _hip_solver(hip, init, trace=True, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+        finally:
+            os.environ.pop("SVNICP_ACCUM", None)
+        out[mode] = (s.get_particles(), s.get_trace()["corr"], s.get_trace()["H"], s.get_ambiguous_steps())
+    assert out["f64"][3] == -1 and out["valu"][3] >= 0 and out["mfma"][3] >= 0
+    n_steps = 6 * ((P + 63) // 64) * 6000
+    assert out["mfma"][3] < 0.5 * n_steps or K == 1, "the MFMA search should decide most wave steps itself"
+    for mode in ("valu", "mfma"):
+        assert np.array_equal(out["f64"][1], out[mode][1]), mode
+        assert np.array_equal(out["f64"][2], out[mode][2]), mode
+        assert np.array_equal(out["f64"][0], out[mode][0]), mode
 
 
 def test_exact_ties_lowest_index_wins(hip, orc):

@@ -59,8 +59,9 @@ struct svnicp_ctx {
   DevBuf<int32_t> pool_i, cand_idx, trcorr, torig, pool2, fail_list;
   DevBuf<float> txf, tyf, tzf, cmaxb;
   DevBuf<float4> tablef, tablea;
+  DevBuf<uint8_t> kbest;
   DevBuf<int> ambig;
-  int accum_mode = 2;  // 0 f64 baseline, 1 f32 VALU search, 2 f32 MFMA search
+  int accum_mode = 3;  // 0 f64 baseline, 1 f32 VALU search, 2 fused f32 MFMA search, 3 MFMA search + accumulate kernels
   DevBuf<unsigned long long> emax;
   DevBuf<int> fail_count;
   // stage A variant: 0 = streaming only (knn_topk), 1 = seeded f32 scan (knn_scan), 2 = pruned tiles (knn_tiles)
@@ -201,7 +202,7 @@ void svnicp_destroy(svnicp_ctx* c) {
   for (auto* b : dbl) b->release();
   c->eul.release(); c->opt.release(); c->uctl.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
-  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->kbest.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->pev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -365,8 +366,9 @@ int svnicp_align_begin(svnicp_ctx* c) {
   HIPCHK(c, c->table.ensure((size_t)B * c->K * 3));
   {
     const char* v1 = getenv("SVNICP_ACCUM_V1");  // A/B switches for tests and profiling
-    const char* am = getenv("SVNICP_ACCUM");     // f64 | valu | mfma
-    c->accum_mode = 2;
+    const char* am = getenv("SVNICP_ACCUM");     // f64 | valu | mfma | split
+    c->accum_mode = 3;
+    if (am && !strcmp(am, "mfma")) c->accum_mode = 2;
     if (am && !strcmp(am, "valu")) c->accum_mode = 1;
     if ((am && !strcmp(am, "f64")) || (v1 && v1[0] == '1')) c->accum_mode = 0;
   }
@@ -379,14 +381,16 @@ int svnicp_align_begin(svnicp_ctx* c) {
   if (nshard > 0) {
     c->plan = plan_accumulate(nshard, B, c->K, c->num_cus, c->accum_mode);
     if (getenv("SVNICP_DEBUG"))
-      fprintf(stderr, "[svnicp] stage-B plan: mode=%d PW=%d WP=%d TP=%d grid=%dx%d tiles/block=%d smem=%zu\n", c->plan.f32,
-              c->plan.PW, c->plan.WP, c->plan.TP, c->plan.grid_x, c->plan.grid_y, c->plan.tiles_per_block, c->plan.smem);
+      fprintf(stderr, "[svnicp] stage-B plan: mode=%d PW=%d WP=%d TP=%d grid=%dx%d tiles/block=%d smem=%zu sgrid=%d pts/block=%d/%d\n", c->plan.f32,
+              c->plan.PW, c->plan.WP, c->plan.TP, c->plan.grid_x, c->plan.grid_y, c->plan.tiles_per_block, c->plan.smem,
+              c->plan.sgrid_x, c->plan.spts_per_block, c->plan.pts_per_block);
     HIPCHK(c, c->partial.ensure((size_t)c->plan.grid_x * c->plan.Ppad * kNSums));
   } else {
     c->plan = AccumPlan{};
-    c->plan.f32 = c->accum_mode == 2 ? 1 : c->accum_mode;
+    c->plan.f32 = c->accum_mode >= 2 ? 1 : c->accum_mode;
   }
-  if (c->plan.f32 == 2) HIPCHK(c, c->tablea.ensure((size_t)B * 128));
+  if (c->plan.f32 >= 2) HIPCHK(c, c->tablea.ensure((size_t)B * 128));
+  if (c->plan.f32 == 3) HIPCHK(c, c->kbest.ensure((size_t)B * c->plan.Ppad));
   else HIPCHK(c, c->tablef.ensure((size_t)B * c->K));
   if (c->prm.record_trace) {
     HIPCHK(c, c->trcorr.ensure((size_t)I * P * B));
@@ -470,7 +474,7 @@ int svnicp_build_candidate_table(svnicp_ctx* c) {
   if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_build_candidate_table: call svnicp_align_begin first");
   if (bind(c)) return SVNICP_ERR_HIP;
   HIPCHK(c, prof_begin(c, KC_TABLE));
-  if (c->plan.f32 == 2)
+  if (c->plan.f32 >= 2)
     HIPCHK(c, launch_build_table3(c->cand_idx.p, c->B, c->K, c->tgt.p, c->M, c->table.p, c->tablea.p, c->cmaxb.p, c->stream));
   else
     HIPCHK(c, launch_build_table2(c->cand_idx.p, c->B, c->K, c->tgt.p, c->M, c->table.p, c->tablef.p, c->cmaxb.p, c->stream));
@@ -489,7 +493,7 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   if (nshard <= 0) return SVNICP_OK;
   if (bind(c)) return SVNICP_ERR_HIP;
   AccumArgs a{};
-  a.src = c->src.p; a.table = c->table.p; a.tablef = c->tablef.p; a.tablea = c->tablea.p; a.cmax = c->cmaxb.p; a.ambig_count = c->ambig.p;
+  a.src = c->src.p; a.table = c->table.p; a.tablef = c->tablef.p; a.tablea = c->tablea.p; a.kbest = c->kbest.p; a.cmax = c->cmaxb.p; a.ambig_count = c->ambig.p;
   a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K;
   a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
   a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;

@@ -104,12 +104,17 @@ struct AccumArgs {
   const int* ctl;       // ctl[0] = stop flag
   int32_t* corr;        // optional trace [P][B] (this iteration), or nullptr
   int svgd;             // SVGD-ICP mode: slot 4 of the sums counts non-zero rows (SVGDICP.cpp:404)
+  uint8_t* kbest;       // split variant: winner index per (source point, particle of the shard), [B][Ppad]
+  int pts_per_block, spts_per_block;  // split variant: source points per workgroup (accumulate / search kernel)
 };
-struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K; int64_t n_tiles; size_t smem; };
-// f32: 0 = float64 baseline, 1 = float32 VALU search, 2 = float32 MFMA search (falls back to 1 when K > 128 or P <= 8)
+struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem; };
+// f32: 0 = float64 baseline, 1 = float32 VALU search, 2 = float32 MFMA search fused with the accumulation,
+// 3 = MFMA search kernel + accumulation kernel (2 and 3 fall back to 1 when K > 128 or P <= 8)
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32);
 int mfma_occupancy_blocks(int PW, int WP, int K, size_t smem);
 hipError_t launch_accumulate_mfma(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);
+hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);
+void split_occupancy_blocks(int PW, int WP, int K, size_t smem, int* search, int* accum);
 hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
                                float4* tablea, float* cmax, hipStream_t st);
 hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,

@@ -25,6 +25,7 @@
 // LDS with one address per lane group (broadcast), rows padded to an odd stride so that distinct
 // rows never share a bank.  Each lane keeps its 22 accumulators in VGPRs for the whole launch;
 // cross-lane/wave/block reduction happens once at the end, in a fixed order (deterministic).
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -434,9 +435,9 @@ static int occupancy_blocks(const AccumPlan& pl) {
 
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32) {
   AccumPlan pl{};
-  if (f32 == 2 && (K > 128 || n_particles <= 8)) f32 = 1;  // MFMA tiles: 16 particles wide, 128 candidate rows
+  if (f32 >= 2 && (K > 128 || n_particles <= 8)) f32 = 1;  // MFMA tiles: 16 particles wide, 128 candidate rows
   pl.f32 = f32;
-  int PW = f32 == 2 ? 16 : 8;
+  int PW = f32 >= 2 ? 16 : 8;
   while (PW < 64 && PW < n_particles) PW <<= 1;
   int WP = 1;
   if (PW == 64) { WP = (n_particles + 63) / 64; if (WP >= 3) WP = 4; }
@@ -447,6 +448,32 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
   const int BW = 64 / PW, WB = 4 / WP;
   const int pass = BW * WB;                  // points per workgroup pass
   pl.RS = (3 * K) | 1;
+  if (f32 == 3) {  // split variant: no LDS tiles; each kernel gets one resident round of workgroups (search: two)
+    const int64_t steps = (B + pass - 1) / pass;
+    auto size_grid = [&](int wg_per_cu, int* gx, int* ppb) {
+      int64_t want = (int64_t)num_cus * wg_per_cu / (pl.grid_y > 0 ? pl.grid_y : 1);
+      if (want < 1) want = 1;
+      const int64_t g = steps < want ? steps : want;
+      const int64_t spb = (steps + g - 1) / g;     // wave steps per workgroup
+      *ppb = (int)(spb * pass);
+      *gx = (int)((B + *ppb - 1) / *ppb);
+    };
+    pl.smem = (size_t)(WB - 1) * per_wg * kNSums * sizeof(double);
+    int occ_s = 4, occ_a = 3;
+    split_occupancy_blocks(PW, WP, K, pl.smem, &occ_s, &occ_a);
+    if (const char* e = getenv("SVNICP_WGPCU")) {  // profiling knob: "<search>,<accumulate>" workgroups per CU
+      int x = 0, y = 0;
+      if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 1 && x <= 16 && y >= 1 && y <= 16) { occ_s = x; occ_a = y; }
+    }
+    else {  // measured at C3: the barrier-free search kernel balances best with two rounds of smaller workgroups;
+      occ_s *= 2;                        // the accumulate kernel pays per workgroup in k_reduce_partials: 3 per CU
+      if (occ_a > 3) occ_a = 3;
+    }
+    size_grid(occ_a, &pl.grid_x, &pl.pts_per_block);
+    size_grid(occ_s, &pl.sgrid_x, &pl.spts_per_block);
+    pl.TP = pass; pl.n_tiles = 0; pl.tiles_per_block = 0;
+    return pl;
+  }
   // bytes per staged source point: baseline = padded f64 row + point; f32 variant = K float4 + point + anchor + C_b
   const size_t per_pt = f32 == 2 ? (size_t)(2048 + 24 + 24 + 4)
                        : f32 ? ((size_t)((K + 3) & ~3) * 16 + 24 + 24 + 4) : ((size_t)(pl.RS + 3) * 8);
@@ -482,6 +509,8 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st) {
   a.TP = plan.TP; a.RS = plan.RS; a.tiles_per_block = plan.tiles_per_block; a.n_tiles = plan.n_tiles;
   a.Ppad = plan.Ppad;
+  a.pts_per_block = plan.pts_per_block; a.spts_per_block = plan.spts_per_block;
+  if (plan.f32 == 3) return launch_accumulate_split(plan, a, st);
   if (plan.f32 == 2) return launch_accumulate_mfma(plan, a, st);
   switch (plan.PW) {
     case 8: return launch_t<8, 1>(plan, a, st);

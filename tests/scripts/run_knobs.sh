@@ -4,9 +4,8 @@ w=${1:-C3}
 run() { echo "== $*" >> gpurun_out/knobs.log; env "$@" SVNICP_DEBUG=1 timeout -k 10 200 python tests/gpu_time_knn.py $w 2>&1 | grep -E "stage-B plan|stage_a" | tail -2 >> gpurun_out/knobs.log; }
 : > gpurun_out/knobs.log
 run X=0
-run SVNICP_WGPCU=2
-run SVNICP_WGPCU=3
-run SVNICP_TP=8
-run SVNICP_TP=32
-run SVNICP_TP=32 SVNICP_WGPCU=3
-run SVNICP_ACCUM=valu
+run SVNICP_WGPCU=4,3
+run SVNICP_WGPCU=5,4
+run SVNICP_WGPCU=10,4
+run SVNICP_WGPCU=5,8
+run SVNICP_WGPCU=15,12

@@ -15,9 +15,10 @@ import csv, glob, collections
 for f in sorted(glob.glob("$out/p*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
+        k = r["Kernel_Name"]; k = "search" if "k_stein_search" in k else "accum_w" if "k_stein_accumulate" in k else "knn_tiles" if "k_knn_tiles" in k else None
+        if k is None: continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
     for k, d in acc.items():
-        if "accumulate" in k or "knn_tiles" in k:
+        if True:
             print(f.split("/")[-3], k, {c: v for c, v in d.items()})
 PY

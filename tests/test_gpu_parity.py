@@ -230,20 +230,24 @@ def test_stage_b_f32_search_is_bit_identical_to_f64_kernel(hip, P, full, K):
     init = hip.scans.make_particles(P, seed=P) * 0.5
     cfg = dict(iterations=6, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=full)
     out = {}
-    for mode in ("f64", "valu", "mfma"):
+    for mode in ("f64", "valu", "mfma", "split"):
         os.environ["SVNICP_ACCUM"] = mode
         try:
             s = _hip_solver(hip, init, trace=True, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
         finally:
             os.environ.pop("SVNICP_ACCUM", None)
         out[mode] = (s.get_particles(), s.get_trace()["corr"], s.get_trace()["H"], s.get_ambiguous_steps())
-    assert out["f64"][3] == -1 and out["valu"][3] >= 0 and out["mfma"][3] >= 0
+    assert out["f64"][3] == -1 and out["valu"][3] >= 0 and out["mfma"][3] >= 0 and out["split"][3] == out["mfma"][3]
     n_steps = 6 * ((P + 63) // 64) * 6000
     assert out["mfma"][3] < 0.5 * n_steps or K == 1, "the MFMA search should decide most wave steps itself"
-    for mode in ("valu", "mfma"):
-        assert np.array_equal(out["f64"][1], out[mode][1]), mode
+    for mode in ("valu", "mfma", "split"):
+        assert np.array_equal(out["f64"][1], out[mode][1]), mode   # correspondences: always identical
+    for mode in ("valu", "mfma"):                                  # same tiling as the f64 kernel: same summation order
         assert np.array_equal(out["f64"][2], out[mode][2]), mode
         assert np.array_equal(out["f64"][0], out[mode][0]), mode
+    # the split variant partitions the source points differently (no LDS tiles): same terms, other order
+    np.testing.assert_allclose(out["split"][2], out["f64"][2], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(out["split"][0], out["f64"][0], rtol=0, atol=1e-9)
 
 
 def test_exact_ties_lowest_index_wins(hip, orc):

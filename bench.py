@@ -12,10 +12,10 @@ keeps the clouds and shards 128·N particles 128 per GPU (weak scaling in the pa
 one all-gather of 176 B per particle per iteration over RCCL.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      — the dominant kernel against the HBM roof (the contract's form), from live
-                  hipEvent timings on the library's stream,
-  roofline_valu — the same kernel against the f64 vector-ALU roof, which is what actually binds
-                  a brute-force NN search, and per-kernel details,
+  roofline      — the dominant kernel (k_stein_search_mfma at C3) against the dense f32 MFMA peak, from
+                  live hipEvent timings on the library's stream,
+  roofline_hbm / roofline_valu — the same kernel against the other roofs (the nearest-candidate search is
+                  bound by vector/matrix issue, not by HBM: SURVEY.md §8d), and per-kernel details,
   cpu_baseline  — the CPU oracle ("port": oracle/svnicp_oracle.c, OpenMP) timed on this box's host
                   cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -35,6 +35,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_VALU_PEAK_TF = 78.6    # MI355X f64 vector peak (FMA counted as 2 flop); 39.3 T non-fused op/s
+F32_MFMA_PEAK_TF = 157.3   # MI355X dense f32-input MFMA peak (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
 
 
 def parse():
@@ -153,7 +154,13 @@ def main():
         # per point-pair distance of the reference's brute force; bytes = clouds/candidates in + results out.
         work = {
             "stage_a_knn": dict(bytes=24.0 * (B + M) + 12.0 * B * K, flops=8.0 * B * M),
-            "k_stein_accumulate": dict(bytes=24.0 * B + 24.0 * B * K, flops=8.0 * P * B * K),
+            # split stage B: the search kernel reads the float32 candidate rows (16 B each) and the source points and
+            # writes one winner byte per (point, particle); the accumulate kernel reads the bytes, the source points
+            # and one winner (24 B) per pair.  Fused variants: everything is in the k_stein_accumulate class.
+            "k_stein_search": dict(bytes=16.0 * B * K + 24.0 * B + 1.0 * P * B, flops=8.0 * P * B * K),
+            "k_stein_accumulate": dict(bytes=(24.0 * B + 25.0 * P * B) if kernel_ms.get("k_stein_search", (0, 0))[1]
+                                       else (24.0 * B + 24.0 * B * K),
+                                       flops=(60.0 * P * B) if kernel_ms.get("k_stein_search", (0, 0))[1] else 8.0 * P * B * K),
         }
         traffic = {}
         try:
@@ -163,28 +170,40 @@ def main():
             pass
         details = {}
         for k, (ms, n) in kernel_ms.items():
+            if n == 0:
+                continue
             d = {"launches_per_registration": n // a.steps, "avg_launch_ms": ms / max(n, 1),
                  "ms_per_registration": ms / a.steps}
             if k in work:
                 avg_s = ms / max(n, 1) * 1e-3
                 d["alg_GBps"] = work[k]["bytes"] / avg_s / 1e9
-                d["alg_f64_TFLOPs"] = work[k]["flops"] / avg_s / 1e12
+                d["alg_TFLOPs"] = work[k]["flops"] / avg_s / 1e12
             details[k] = d
         dom = max(work, key=lambda k: kernel_ms.get(k, (0, 0))[0])
         avg_s = kernel_ms[dom][0] / max(kernel_ms[dom][1], 1) * 1e-3
-        ach = work[dom]["bytes"] / avg_s / 1e9
-        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic.get(dom, {}).get("bytes") if P == 128 else None,
-                           "note": "nearest-neighbour search is VALU-bound, not HBM-bound (SURVEY.md §8d): see "
-                                   "roofline_valu; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch "
-                                   "(profiles/traffic.json)"}
+        gbs = work[dom]["bytes"] / avg_s / 1e9
         tf = work[dom]["flops"] / avg_s / 1e12
-        out["roofline_valu"] = {"kernel": dom, "bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TF,
-                                "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TF,
-                                "note": "algorithmic flops of the reference's f64 brute force (8 per pair) per launch "
-                                        "time; the kernels reach them with exact float32 pre-filters / pruning, so "
-                                        "this is an effective rate, not an instruction count"}
+        tr = traffic.get(dom, {}).get("bytes") if P == 128 else None
+        hbm = {"kernel": dom, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+               "traffic": tr}
+        if dom == "k_stein_search":
+            # the dominant kernel's scores come off the f32 matrix cores: price it against the dense f32 MFMA peak with
+            # the ALGORITHMIC flops of the reference's brute force (8 per candidate-particle pair)
+            out["roofline"] = {"kernel": "k_stein_search_mfma", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF,
+                               "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF, "traffic": tr,
+                               "note": "f32 MFMA tiles + 3 VALU tracking ops per score share the SIMD issue (PMC in "
+                                       "profiles/): VALU 60 % + MFMA 28 % busy; the HBM view of the same kernel is roofline_hbm; "
+                                       "traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/traffic.json)"}
+            out["roofline_hbm"] = hbm
+        else:
+            hbm["note"] = ("nearest-neighbour search is VALU-bound, not HBM-bound (SURVEY.md §8d): see roofline_valu; traffic = "
+                           "rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/traffic.json)")
+            out["roofline"] = hbm
+            out["roofline_valu"] = {"kernel": dom, "bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TF,
+                                    "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TF,
+                                    "note": "algorithmic flops of the reference's f64 brute force (8 per pair) per launch "
+                                            "time; the kernels reach them with exact float32 pre-filters / pruning, so "
+                                            "this is an effective rate, not an instruction count"}
         out["kernels"] = details
 
     if rank == 0 and world == 1 and a.cpu_sample > 0:

@@ -158,10 +158,13 @@ int svnicp_get_knn_survivors(svnicp_ctx *ctx, int32_t *outB);
 int svnicp_get_ambiguous_steps(svnicp_ctx *ctx, int *out);
 /* bench hook: when on, every kernel launch of an align is bracketed by hipEvents on the
  * context's stream; svnicp_get_kernel_ms then returns the summed milliseconds and launch counts
- * per kernel class {stage A (ordering + k_knn_tiles/k_knn_scan + fallback), k_build_table2,
- * k_stein_accumulate*, k_reduce_partials, k_particle_update} of the LAST align. */
+ * per kernel class of the LAST align, SVNICP_KERNEL_CLASSES entries in this order:
+ *   0 stage A (ordering + k_knn_tiles/k_knn_scan + fallback)   1 k_build_table*
+ *   2 k_stein_search_mfma (split stage B only)                 3 k_stein_accumulate* (fused variants: whole stage B)
+ *   4 k_reduce_partials                                        5 k_particle_update / k_upd_* */
+#define SVNICP_KERNEL_CLASSES 6
 int svnicp_set_profile(svnicp_ctx *ctx, int on);
-int svnicp_get_kernel_ms(svnicp_ctx *ctx, double *ms5, int32_t *launches5);
+int svnicp_get_kernel_ms(svnicp_ctx *ctx, double *ms6, int32_t *launches6);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,9 @@ struct svnicp_ctx {
   DevBuf<float> txf, tyf, tzf, cmaxb;
   DevBuf<float4> tablef, tablea;
   DevBuf<uint8_t> kbest;
+  DevBuf<double> sl_d, fail_tau;
+  DevBuf<int32_t> sl_i;
+  int sliced_max = 0;  // set at align_begin (kFallbackSlicedMax or SVNICP_FALLBACK_SLICED_MAX)
   DevBuf<int> ambig;
   int accum_mode = 3;  // 0 f64 baseline, 1 f32 VALU search, 2 fused f32 MFMA search, 3 MFMA search + accumulate kernels
   DevBuf<unsigned long long> emax;
@@ -97,9 +100,10 @@ static int fused_update_max_p() {         // A/B switch for tests and profiling:
   return v;
 }
 constexpr int kFallbackGrid = 256;  // workgroups of the streaming kernel when it only redoes failed queries
+constexpr int kFallbackSlicedMax = 512;  // up to this many failed queries are redone by target slices (all CUs per query)
 constexpr int kFallbackQW = 2;      // … two queries per wave, so a few hundred failures still run in parallel
 
-enum { KC_KNN = 0, KC_TABLE = 1, KC_ACCUM = 2, KC_REDUCE = 3, KC_UPDATE = 4, KC_COUNT = 5 };
+enum { KC_KNN = 0, KC_TABLE = 1, KC_SEARCH = 2, KC_ACCUM = 3, KC_REDUCE = 4, KC_UPDATE = 5, KC_COUNT = SVNICP_KERNEL_CLASSES };
 
 static hipError_t prof_begin(svnicp_ctx* c, int cls) {
   if (!c->profile) return hipSuccess;
@@ -202,7 +206,7 @@ void svnicp_destroy(svnicp_ctx* c) {
   for (auto* b : dbl) b->release();
   c->eul.release(); c->opt.release(); c->uctl.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
-  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->kbest.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->kbest.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->pev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -355,8 +359,19 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, c->pool2.ensure((size_t)B * c->scan_S2));
     HIPCHK(c, c->fail_list.ensure((size_t)B));
     HIPCHK(c, c->fail_count.ensure(1));
+    HIPCHK(c, c->fail_tau.ensure((size_t)B));
     HIPCHK(c, c->pool_d.ensure((size_t)kFallbackGrid * 4 * kFallbackQW * c->S));   // fallback rows only
     HIPCHK(c, c->pool_i.ensure((size_t)kFallbackGrid * 4 * kFallbackQW * c->S));
+    {
+      const char* e = getenv("SVNICP_FALLBACK_SLICED_MAX");  // test switch: 0 forces the plain list-mode fallback
+      c->sliced_max = e ? atoi(e) : kFallbackSlicedMax;
+      if (c->sliced_max < 0) c->sliced_max = 0;
+      if (c->sliced_max > kFallbackSlicedMax) c->sliced_max = kFallbackSlicedMax;
+    }
+    if (c->sliced_max > 0) {
+      HIPCHK(c, c->sl_d.ensure((size_t)c->sliced_max * knn_slice_count(c->K) * c->K));
+      HIPCHK(c, c->sl_i.ensure((size_t)c->sliced_max * knn_slice_count(c->K) * c->K));
+    }
   } else {
     HIPCHK(c, c->pool_d.ensure((size_t)B * c->S));
     HIPCHK(c, c->pool_i.ensure((size_t)B * c->S));
@@ -422,6 +437,21 @@ int svnicp_align_begin(svnicp_ctx* c) {
   return SVNICP_OK;
 }
 
+// redo the queries listed in fail_list: few -> target-sliced scan + merge, many -> one wave per two queries
+static hipError_t launch_fallback(svnicp_ctx* c, KnnArgs a) {
+  a.qlist = c->fail_list.p; a.qlist_count = c->fail_count.p; a.list_grid = kFallbackGrid; a.list_qw = kFallbackQW;
+  a.slice_max_queries = c->sliced_max; a.slices = 0;
+  hipError_t e = launch_knn_topk(a, c->stream);  // returns at once unless the list is longer than slice_max_queries
+  if (e != hipSuccess || c->sliced_max <= 0) return e;
+  a.slices = knn_slice_count(c->K);
+  a.merge_n = 1;
+  while (a.merge_n < a.slices * c->K) a.merge_n <<= 1;
+  a.sl_d = c->sl_d.p; a.sl_i = c->sl_i.p;
+  e = launch_knn_topk(a, c->stream);
+  if (e != hipSuccess) return e;
+  return launch_knn_merge_slices(a, c->stream);
+}
+
 int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
   CTX_CHECK(c);
   if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_stage_candidates: call svnicp_align_begin first");
@@ -443,12 +473,12 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
       k.torig = c->torig.p; k.tile_box = c->tile_box.p; k.emax_bits = c->emax.p;
       k.M = c->M; k.Mp = c->Mp; k.n_tiles = (int)(c->Mp / 512); k.b_lo = b_lo; k.b_hi = b_hi; k.K = c->K; k.S2 = c->scan_S2;
       k.pool = c->pool2.p; k.out_idx = c->cand_idx.p; k.out_d2 = c->cand_d2.p;
-      k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p;
+      k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p; k.fail_tau = c->fail_tau.p;
+      a.qthr = c->fail_tau.p;
       if (c->prm.record_trace) { HIPCHK(c, c->stat_n.ensure((size_t)c->B)); k.stat_n = c->stat_n.p; }
       HIPCHK(c, hipMemsetAsync(c->fail_count.p, 0, sizeof(int), c->stream));
       HIPCHK(c, launch_knn_tiles(k, c->stream));
-      a.qlist = c->fail_list.p; a.qlist_count = c->fail_count.p; a.list_grid = kFallbackGrid; a.list_qw = kFallbackQW;
-      HIPCHK(c, launch_knn_topk(a, c->stream));
+      HIPCHK(c, launch_fallback(c, a));
     }
   } else if (c->use_scan) {
     KnnScanArgs k{};
@@ -460,8 +490,7 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
     HIPCHK(c, hipMemsetAsync(c->fail_count.p, 0, sizeof(int), c->stream));
     HIPCHK(c, launch_knn_scan(k, c->stream));
     // redo the (rare) queries whose seeded threshold was too tight: streaming kernel, list mode
-    a.qlist = c->fail_list.p; a.qlist_count = c->fail_count.p; a.list_grid = kFallbackGrid; a.list_qw = kFallbackQW;
-    HIPCHK(c, launch_knn_topk(a, c->stream));
+    HIPCHK(c, launch_fallback(c, a));
   } else {
     HIPCHK(c, launch_knn_topk(a, c->stream));
   }
@@ -498,6 +527,11 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
   a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;
   a.svgd = c->prm.mode == SVNICP_MODE_SVGD ? 1 : 0;
+  if (c->plan.f32 == 3) {
+    HIPCHK(c, prof_begin(c, KC_SEARCH));
+    HIPCHK(c, launch_search_split(c->plan, a, c->stream));
+    HIPCHK(c, prof_end(c));
+  }
   HIPCHK(c, prof_begin(c, KC_ACCUM));
   HIPCHK(c, launch_accumulate(c->plan, a, c->stream));
   HIPCHK(c, prof_end(c));
@@ -661,7 +695,7 @@ int svnicp_set_profile(svnicp_ctx* c, int on) {
   return SVNICP_OK;
 }
 
-int svnicp_get_kernel_ms(svnicp_ctx* c, double* ms5, int32_t* launches5) {
+int svnicp_get_kernel_ms(svnicp_ctx* c, double* ms5, int32_t* launches5) {  // SVNICP_KERNEL_CLASSES entries each
   NEED_RESULT(c);
   if (!c->profile) return fail(c, SVNICP_ERR_INVALID, "svnicp_get_kernel_ms: profiling is off (svnicp_set_profile)");
   if (bind(c)) return SVNICP_ERR_HIP;

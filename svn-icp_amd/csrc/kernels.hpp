@@ -21,8 +21,17 @@ struct KnnArgs {
   const int* qlist_count;   // device scalar: number of entries of qlist
   int list_grid;            // list mode: number of workgroups
   int list_qw;              // list mode: queries per wave chunk (pool rows = list_grid*4*list_qw)
+  // sliced list mode (lists of at most slice_max_queries): every listed query is scanned by `slices` waves over
+  // disjoint target ranges; per-slice top-K lists in sl_d/sl_i [slice_max_queries][slices][K], merged by
+  // k_knn_merge_slices (merge_n = power of two >= slices*K).  slices = 0: plain list mode.
+  int slices, slice_max_queries, merge_n;
+  double* sl_d;
+  int32_t* sl_i;
+  const double* qthr;  // sliced list mode, optional: starting threshold of each listed query (from k_knn_tiles)
 };
 int knn_pool_size(int K);
+int knn_slice_count(int K);
+hipError_t launch_knn_merge_slices(const KnnArgs& a, hipStream_t st);
 int64_t knn_padded_targets(int64_t M);
 
 // ---------------- Stage A fast variant (knn_scan.hip) ----------------
@@ -71,6 +80,7 @@ struct KnnTilesArgs {
   int32_t* fail_list;
   int* fail_count;
   int32_t* stat_n;                // optional [B]: survivors of the f32 filter per query (first pass)
+  double* fail_tau;   // optional [B]: a valid threshold (>= K-th distance) of each failed query, +inf if none
 };
 bool knn_tiles_applicable(int64_t Mp, int K);
 hipError_t launch_knn_tiles(const KnnTilesArgs& a, hipStream_t st);
@@ -113,7 +123,8 @@ struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f3
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32);
 int mfma_occupancy_blocks(int PW, int WP, int K, size_t smem);
 hipError_t launch_accumulate_mfma(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);
-hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);
+hipError_t launch_search_split(const AccumPlan& plan, AccumArgs a, hipStream_t st);         // split variant, kernel 1
+hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);  // split variant, kernel 2 (via launch_accumulate)
 void split_occupancy_blocks(int PW, int WP, int K, size_t smem, int* search, int* accum);
 hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
                                float4* tablea, float* cmax, hipStream_t st);

@@ -368,7 +368,12 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
       ok = m >= K && m <= SL;
     }
     if (!ok) {
-      if (lane == 0) { const int slot = atomicAdd(a.fail_count, 1); a.fail_list[slot] = (int32_t)b; }
+      if (lane == 0) {
+        const int slot = atomicAdd(a.fail_count, 1);
+        a.fail_list[slot] = (int32_t)b;
+        // tau has K witnesses, so the fallback may start from it; fewer than K survivors means it cannot be trusted
+        if (a.fail_tau) a.fail_tau[slot] = (n <= S2 && m < K) ? __builtin_huge_val() : tau;
+      }
       wave_sync();
       continue;
     }

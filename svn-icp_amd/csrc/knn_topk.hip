@@ -99,10 +99,18 @@ __global__ __launch_bounds__(256) void k_knn_topk(KnnArgs a) {
 
   // direct mode: queries b_lo..b_hi, one 64-query chunk per wave.  list mode (fallback of
   // knn_scan.hip): queries qlist[0..*qlist_count), chunks strided over the fixed grid.
+  // sliced list mode (few failed queries): work item w = (failed query w / slices, target slice w % slices), one
+  // per wave chunk; the per-slice top-K lists go to sl_d / sl_i and k_knn_merge_slices finishes the query.  A list
+  // longer than slice_max_queries is left to the plain list mode (and vice versa): both launches are always issued.
   const bool list_mode = a.qlist != nullptr;
-  const int64_t n_queries = list_mode ? (int64_t)*a.qlist_count : (a.b_hi - a.b_lo);
-  const int cq = list_mode ? a.list_qw : QW;  // queries per chunk: few in list mode, so failed queries spread over many waves
+  const bool sliced = list_mode && a.slices > 0;
+  const int64_t n_listed = list_mode ? (int64_t)*a.qlist_count : 0;
+  if (list_mode && ((n_listed <= a.slice_max_queries) != sliced)) return;  // the other launch owns this regime
+  const int64_t n_queries = sliced ? n_listed * a.slices : list_mode ? n_listed : (a.b_hi - a.b_lo);
+  const int cq = sliced ? 1 : list_mode ? a.list_qw : QW;  // queries per chunk: few in list mode, so failed queries spread over many waves
   const int64_t n_chunks = (n_queries + cq - 1) / cq;
+  const int64_t tiles_total = a.Mp / STEP;
+  const int64_t tiles_per_slice = sliced ? (tiles_total + a.slices - 1) / a.slices : tiles_total;
   const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
   const int64_t total_waves = (int64_t)gridDim.x * WAVES;
 
@@ -114,13 +122,13 @@ __global__ __launch_bounds__(256) void k_knn_topk(KnnArgs a) {
       QSlot s;
       int64_t b = 0;
       if (lane < nq) {
-        b = list_mode ? (int64_t)a.qlist[c0 + lane] : a.b_lo + c0 + lane;
+        b = sliced ? (int64_t)a.qlist[c0 / a.slices] : list_mode ? (int64_t)a.qlist[c0 + lane] : a.b_lo + c0 + lane;
         const double sx = a.src[3 * b], sy = a.src[3 * b + 1], sz = a.src[3 * b + 2];
         const double* R = a.pose.R0;
         s.x = (sx * R[0] + sy * R[1] + sz * R[2]) + a.pose.t0[0];
         s.y = (sx * R[3] + sy * R[4] + sz * R[5]) + a.pose.t0[1];
         s.z = (sx * R[6] + sy * R[7] + sz * R[8]) + a.pose.t0[2];
-        s.thr = __builtin_huge_val();
+        s.thr = (sliced && a.qthr) ? a.qthr[c0 / a.slices] : __builtin_huge_val();
       } else {
         s.x = s.y = s.z = 0.0;
         s.thr = -1.0;  // nothing passes d2 <= -1
@@ -131,13 +139,23 @@ __global__ __launch_bounds__(256) void k_knn_topk(KnnArgs a) {
     }
     wave_sync();
 
-    double x[T], y[T], z[T], nx[T], ny[T], nz[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      x[t] = a.tx[t * kWave + lane]; y[t] = a.ty[t * kWave + lane]; z[t] = a.tz[t * kWave + lane];
+    int64_t tile_lo = 0, tile_hi = a.Mp;
+    if (sliced) {
+      tile_lo = (c0 % a.slices) * tiles_per_slice * STEP;
+      tile_hi = tile_lo + tiles_per_slice * STEP;
+      if (tile_hi > a.Mp) tile_hi = a.Mp;
+      if (tile_lo > tile_hi) tile_lo = tile_hi;
     }
-    for (int64_t tile = 0; tile < a.Mp; tile += STEP) {
-      const int64_t nt = (tile + STEP < a.Mp) ? tile + STEP : tile;  // prefetch next tile (or re-read last)
+    double x[T], y[T], z[T], nx[T], ny[T], nz[T];
+    {
+      const int64_t t0 = tile_lo < a.Mp ? tile_lo : 0;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        x[t] = a.tx[t0 + t * kWave + lane]; y[t] = a.ty[t0 + t * kWave + lane]; z[t] = a.tz[t0 + t * kWave + lane];
+      }
+    }
+    for (int64_t tile = tile_lo; tile < tile_hi; tile += STEP) {
+      const int64_t nt = (tile + STEP < tile_hi) ? tile + STEP : tile;  // prefetch next tile (or re-read last)
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         nx[t] = a.tx[nt + t * kWave + lane]; ny[t] = a.ty[nt + t * kWave + lane]; nz[t] = a.tz[nt + t * kWave + lane];
@@ -190,12 +208,63 @@ __global__ __launch_bounds__(256) void k_knn_topk(KnnArgs a) {
       const int64_t b = qb[q];
       merge_pool(q, lane, K, S, qv, cnt, sd, si, a.pool_d, a.pool_i, (pool_row0 + q) * (int64_t)S);
       const int n = __builtin_amdgcn_readfirstlane(cnt[q]);
-      for (int e = lane; e < K; e += kWave) {
-        const bool in = e < n;
-        a.out_idx[b * K + e] = in ? si[e] : 0;
-        a.out_d2[b * K + e] = in ? sd[e] : 0.0;
+      if (sliced) {  // partial result of this slice, padded with never-selected entries
+        for (int e = lane; e < K; e += kWave) {
+          const bool in = e < n;
+          a.sl_d[c0 * K + e] = in ? sd[e] : __builtin_huge_val();
+          a.sl_i[c0 * K + e] = in ? si[e] : 0x7fffffff;
+        }
+      } else {
+        for (int e = lane; e < K; e += kWave) {
+          const bool in = e < n;
+          a.out_idx[b * K + e] = in ? si[e] : 0;
+          a.out_d2[b * K + e] = in ? sd[e] : 0.0;
+        }
       }
       wave_sync();
+    }
+  }
+}
+
+// sliced list mode, second half: K-way merge of the slices' sorted top-K lists of one failed query.  One wave per
+// query, lane <-> slice: the lists sit in LDS, each lane holds the head of its list, and K rounds of a wave-wide
+// (d², idx) minimum pop the result in order (padding as knn_cpu.cpp:25-26).
+__global__ __launch_bounds__(64) void k_knn_merge_slices(KnnArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int n_listed = *a.qlist_count;
+  if (n_listed > a.slice_max_queries) return;
+  const int K = a.K, NS = a.slices, lane = threadIdx.x;
+  const int n_in = NS * K;
+  double* sd = reinterpret_cast<double*>(smem);
+  int* si = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)n_in);
+  for (int f = blockIdx.x; f < n_listed; f += gridDim.x) {
+    const int64_t b = a.qlist[f];
+    wave_sync();
+    for (int e = lane; e < n_in; e += kWave) { sd[e] = a.sl_d[(int64_t)f * n_in + e]; si[e] = a.sl_i[(int64_t)f * n_in + e]; }
+    wave_sync();
+    int pos = 0;
+    double hd = lane < NS ? sd[lane * K] : __builtin_huge_val();
+    int hi = lane < NS ? si[lane * K] : 0x7fffffff;
+    for (int r = 0; r < K; ++r) {
+      double bd = hd;
+      int bi = hi, bl = lane;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(bd, off, kWave);
+        const int oi = __shfl_xor(bi, off, kWave), ol = __shfl_xor(bl, off, kWave);
+        // exhausted heads are (inf, INT_MAX); equal (d, idx) cannot come from two slices (distinct targets)
+        if (ent_less(od, oi, bd, bi) || (od == bd && oi == bi && ol < bl)) { bd = od; bi = oi; bl = ol; }
+      }
+      if (lane == 0) {
+        const bool in = bi != 0x7fffffff;
+        a.out_idx[b * K + r] = in ? bi : 0;
+        a.out_d2[b * K + r] = in ? bd : 0.0;
+      }
+      if (lane == bl && bi != 0x7fffffff) {
+        ++pos;
+        hd = pos < K ? sd[lane * K + pos] : __builtin_huge_val();
+        hi = pos < K ? si[lane * K + pos] : 0x7fffffff;
+      }
     }
   }
 }
@@ -237,6 +306,25 @@ hipError_t launch_knn_topk(const KnnArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_knn_topk, dim3((unsigned)nb), dim3(256), smem, st, a);
+  return hipGetLastError();
+}
+
+int knn_slice_count(int K) {  // slices x K entries must fit the merge kernel's 8192-entry LDS sort
+  int kp = 1;
+  while (kp < K) kp <<= 1;
+  int ns = 8192 / kp;
+  return ns > 64 ? 64 : (ns < 1 ? 1 : ns);
+}
+
+hipError_t launch_knn_merge_slices(const KnnArgs& a, hipStream_t st) {
+  const size_t smem = (size_t)a.slices * a.K * (sizeof(double) + sizeof(int));
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_merge_slices),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  const int nb = a.slice_max_queries < 512 ? a.slice_max_queries : 512;
+  hipLaunchKernelGGL(k_knn_merge_slices, dim3(nb > 0 ? nb : 1), dim3(64), smem, st, a);
   return hipGetLastError();
 }
 

@@ -366,15 +366,27 @@ void split_occupancy_blocks(int PW, int WP, int K, size_t smem, int* search, int
   }
 }
 
-hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
-  hipError_t e;
+// search kernel, then (launch_accumulate_split) the accumulation kernel; api.hip brackets them separately
+hipError_t launch_search_split(const AccumPlan& plan, AccumArgs a, hipStream_t st) {
+  a.Ppad = plan.Ppad; a.pts_per_block = plan.pts_per_block; a.spts_per_block = plan.spts_per_block;
   switch (plan.PW) {
-    case 16: e = launch_srb<16, 1>(plan, a, st); if (e != hipSuccess) return e; return launch_w<16, 1>(plan, a, st);
-    case 32: e = launch_srb<32, 1>(plan, a, st); if (e != hipSuccess) return e; return launch_w<32, 1>(plan, a, st);
+    case 16: return launch_srb<16, 1>(plan, a, st);
+    case 32: return launch_srb<32, 1>(plan, a, st);
     default:
-      if (plan.WP == 1) { e = launch_srb<64, 1>(plan, a, st); if (e != hipSuccess) return e; return launch_w<64, 1>(plan, a, st); }
-      if (plan.WP == 2) { e = launch_srb<64, 2>(plan, a, st); if (e != hipSuccess) return e; return launch_w<64, 2>(plan, a, st); }
-      e = launch_srb<64, 4>(plan, a, st); if (e != hipSuccess) return e; return launch_w<64, 4>(plan, a, st);
+      if (plan.WP == 1) return launch_srb<64, 1>(plan, a, st);
+      if (plan.WP == 2) return launch_srb<64, 2>(plan, a, st);
+      return launch_srb<64, 4>(plan, a, st);
+  }
+}
+
+hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
+  switch (plan.PW) {
+    case 16: return launch_w<16, 1>(plan, a, st);
+    case 32: return launch_w<32, 1>(plan, a, st);
+    default:
+      if (plan.WP == 1) return launch_w<64, 1>(plan, a, st);
+      if (plan.WP == 2) return launch_w<64, 2>(plan, a, st);
+      return launch_w<64, 4>(plan, a, st);
   }
 }
 

@@ -220,15 +220,16 @@ class _SolverBase:
     def get_gpu_ms(self) -> np.ndarray:
         return self._getd("gpu_ms", 3)
 
-    KERNEL_CLASSES = ("stage_a_knn", "k_build_table", "k_stein_accumulate", "k_reduce_partials", "k_particle_update")
+    KERNEL_CLASSES = ("stage_a_knn", "k_build_table", "k_stein_search", "k_stein_accumulate", "k_reduce_partials",
+                      "k_particle_update")  # include/svnicp_hip.h SVNICP_KERNEL_CLASSES
 
     def set_profile(self, on: bool):
         self._check(self._L.svnicp_set_profile(self._h, int(on)), "svnicp_set_profile")
 
     def get_kernel_ms(self) -> dict:
         """{kernel class: (total ms in the last align, launches)} — hipEvents on the library's stream."""
-        ms = np.zeros(5, np.float64)
-        n = np.zeros(5, np.int32)
+        ms = np.zeros(len(self.KERNEL_CLASSES), np.float64)
+        n = np.zeros(len(self.KERNEL_CLASSES), np.int32)
         self._check(self._L.svnicp_get_kernel_ms(self._h, ms.ctypes.data_as(C.POINTER(C.c_double)),
                                                  n.ctypes.data_as(C.POINTER(C.c_int32))), "svnicp_get_kernel_ms")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.KERNEL_CLASSES)}

@@ -200,20 +200,29 @@ def test_stage_a_variants_bit_exact(hip, orc, B, M, K):
         assert 0 <= fbs["default"] <= max(2, B // 100)  # guaranteed seed + in-kernel overflow recovery
 
 
-def test_stage_a_fallback_on_pool_overflow(hip, orc):
+@pytest.mark.parametrize("sliced_max,K", [(None, 50), ("0", 50), ("100", 50), (None, 128), (None, 7)])
+def test_stage_a_fallback_on_pool_overflow(hip, orc, sliced_max, K):
     """Clustered duplicates: thousands of targets at exactly the same distance overflow the
     candidate pool of every query; all of them must be redone by the streaming fallback and still
-    come out bit-exact (ties broken by lowest index)."""
+    come out bit-exact (ties broken by lowest index).  Both fallback regimes: target-sliced scan +
+    merge (few failures, default here) and one wave per two queries (SVNICP_FALLBACK_SLICED_MAX
+    below the failure count)."""
+    import os
     rng = np.random.default_rng(3)
     centers = rng.normal(size=(6, 3)) * 5
     tgt = np.repeat(centers, 2000, axis=0).astype(np.float32).astype(np.float64)   # M = 12000, 2000 duplicates each
     tgt = tgt[rng.permutation(tgt.shape[0])]
     src = (centers[rng.integers(0, 6, 300)] + rng.normal(size=(300, 3)) * 0.1)
     init = np.zeros((6, 1))
-    cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=50, svn_full_grad=False)
-    s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+    cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
+    if sliced_max is not None:
+        os.environ["SVNICP_FALLBACK_SLICED_MAX"] = sliced_max
+    try:
+        s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+    finally:
+        os.environ.pop("SVNICP_FALLBACK_SLICED_MAX", None)
     assert s.get_knn_fallbacks() == 300
-    oi, od = orc.knn_topk(src, tgt, 50)
+    oi, od = orc.knn_topk(src, tgt, K)
     assert np.array_equal(s.get_candidates().astype(np.int64), oi)
     assert np.array_equal(s.get_candidate_dist2(), od)
 

@@ -114,6 +114,12 @@ struct AccumArgs {
   const int* ctl;       // ctl[0] = stop flag
   int32_t* corr;        // optional trace [P][B] (this iteration), or nullptr
   int svgd;             // SVGD-ICP mode: slot 4 of the sums counts non-zero rows (SVGDICP.cpp:404)
+  // split variant: no f64 candidate table — winners are gathered as tgt[cand[b][k]] (6 MB + 4 B/candidate instead of
+  // 24 B/candidate of HBM traffic), the local frame's origin comes from anchor[b]
+  const double* tgt;    // [M][3]
+  const int32_t* cand;  // [B][K] candidate indices (stage A)
+  const double* anchor; // [B][3] = tgt[cand[b][0]]
+  int64_t M;
   uint8_t* kbest;       // split variant: winner index per (source point, particle of the shard), [B][Ppad]
   int pts_per_block, spts_per_block;  // split variant: source points per workgroup (accumulate / search kernel)
 };
@@ -126,8 +132,9 @@ hipError_t launch_accumulate_mfma(const AccumPlan& plan, const AccumArgs& a, hip
 hipError_t launch_search_split(const AccumPlan& plan, AccumArgs a, hipStream_t st);         // split variant, kernel 1
 hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);  // split variant, kernel 2 (via launch_accumulate)
 void split_occupancy_blocks(int PW, int WP, int K, size_t smem, int* search, int* accum);
+// table may be nullptr (split variant): then only anchor / tablea / cmax are written
 hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
-                               float4* tablea, float* cmax, hipStream_t st);
+                               double* anchor, float4* tablea, float* cmax, hipStream_t st);
 hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
                                float4* tablef, float* cmax, hipStream_t st);
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st);

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(NT, 2) void k_stein_accumulate_mfma(AccumArgs a) {
 // tablea[b][h][lane] = float4 over row blocks rb = 4h..4h+3 of component (lane/16) of candidate 16·rb + lane%16.
 __global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict__ idx, int64_t B, int K,
                                                       const double* __restrict__ tgt, int64_t M, double* __restrict__ table,
-                                                      float4* __restrict__ tablea, float* __restrict__ cmax) {
+                                                      double* __restrict__ anchor, float4* __restrict__ tablea,
+                                                      float* __restrict__ cmax) {
   __shared__ float rowbuf[4][128 * 4];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + wave;
@@ -290,8 +291,10 @@ __global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict_
       int64_t i = idx[b * K + k];
       i = i < 0 ? 0 : (i >= M ? M - 1 : i);
       const double x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
-      double* o = table + ((size_t)b * K + k) * 3;
-      o[0] = x; o[1] = y; o[2] = z;
+      if (table) {
+        double* o = table + ((size_t)b * K + k) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+      }
       cx = (float)(x - a0); cy = (float)(y - a1); cz = (float)(z - a2);
       cc = (float)(((double)cx * cx + (double)cy * cy) + (double)cz * cz);
       cm = __builtin_fmaxf(cm, __builtin_fmaxf(__builtin_fabsf(cx), __builtin_fmaxf(__builtin_fabsf(cy), __builtin_fabsf(cz))));
@@ -303,7 +306,10 @@ __global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict_
     const float o = __shfl_xor(cm, off, kWave);
     cm = (cm != cm || o != o) ? __builtin_nanf("") : __builtin_fmaxf(cm, o);
   }
-  if (lane == 0) cmax[b] = cm;
+  if (lane == 0) {
+    cmax[b] = cm;
+    anchor[3 * b] = a0; anchor[3 * b + 1] = a1; anchor[3 * b + 2] = a2;
+  }
   __builtin_amdgcn_wave_barrier();
   const int mi = lane & 15, mk = lane >> 4;
 #pragma unroll
@@ -381,9 +387,10 @@ hipError_t launch_accumulate_mfma(const AccumPlan& plan, const AccumArgs& a, hip
 }
 
 hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
-                               float4* tablea, float* cmax, hipStream_t st) {
+                               double* anchor, float4* tablea, float* cmax, hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_build_table3, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, idx, B, K, tgt, M, table, tablea, cmax);
+  hipLaunchKernelGGL(k_build_table3, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, idx, B, K, tgt, M, table, anchor, tablea,
+                     cmax);
   return hipGetLastError();
 }
 

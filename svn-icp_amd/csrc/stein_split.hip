@@ -79,7 +79,7 @@ __global__ __launch_bounds__(NT, 4) void k_stein_search_mfma(AccumArgs a) {
     const bool valid = pvalid && inb;
     const int64_t bl = inb ? b : n;
     const double* sp = a.src + 3 * bl;
-    const double* an = a.table + (size_t)bl * K * 3;   // first candidate = anchor of the local frame
+    const double* an = a.anchor + 3 * bl;               // first candidate = origin of the local frame
     const double s0 = sp[0], s1 = sp[1], s2 = sp[2];
     const double T0 = (s0 * Rt[0] + s1 * Rt[1] + s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64
     const double T1 = (s0 * Rt[3] + s1 * Rt[4] + s2 * Rt[5]) + tt[1];
@@ -163,11 +163,14 @@ __global__ __launch_bounds__(NT, 4) void k_stein_search_mfma(AccumArgs a) {
         am &= am - 1;
         const double t0 = rdlane_f64(T0, L), t1 = rdlane_f64(T1, L), t2 = rdlane_f64(T2, L);
         const int bsL = L / PW;
-        const double* r = a.table + (size_t)(n + bsL) * K * 3;
+        const int32_t* ci = a.cand + (size_t)(n + bsL) * K;
         double bd = __builtin_huge_val(), d_first = 0.0;
         int bk = 0x7fffffff;
         for (int k = lane; k < K; k += kWave) {
-          const double dx = t0 - r[3 * k], dy = t1 - r[3 * k + 1], dz = t2 - r[3 * k + 2];
+          int64_t ti = ci[k];
+          ti = ti < 0 ? 0 : (ti >= a.M ? a.M - 1 : ti);
+          const double* r = a.tgt + 3 * ti;
+          const double dx = t0 - r[0], dy = t1 - r[1], dz = t2 - r[2];
           const double d = (dx * dx + dy * dy) + dz * dz;   // knn_cpu.cpp:43-50 order, unfused
           if (k == 0) d_first = d;
           if (d < bd || (d == bd && k < bk)) { bd = d; bk = k; }
@@ -223,13 +226,20 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
   const int64_t blk_hi = (blk_lo + a.pts_per_block < a.B) ? blk_lo + a.pts_per_block : a.B;
   constexpr int STEP = WB * BW;
 
-  // three-stage pipeline: winner byte of point n+2·STEP | winner coordinates of n+STEP | sums of n
+  // four-stage pipeline: winner byte of point n+3·STEP | its target index (n+2·STEP) | winner coordinates and Ts
+  // (n+STEP) | sums of n — every load has a full step of other work between issue and use
   struct Stage { double s0, s1, s2, T0, T1, T2, q0, q1, q2; bool valid; };
   auto load_kb = [&](int64_t n) -> int {
     const int64_t b = n + bs;
     return (pvalid && b < blk_hi) ? (int)a.kbest[(size_t)b * a.Ppad + pidx] : 0;
   };
-  auto fetch = [&](int64_t n, int kb, Stage& st) {
+  auto load_ti = [&](int64_t n, int kb) -> int64_t {  // target index of the winner; clamped like k_build_table3
+    const int64_t b = n + bs;
+    const int64_t bl = b < blk_hi ? b : blk_lo;
+    int64_t ti = a.cand[(size_t)bl * K + kb];
+    return ti < 0 ? 0 : (ti >= a.M ? a.M - 1 : ti);
+  };
+  auto fetch = [&](int64_t n, int64_t ti, int kb, Stage& st) {
     const int64_t b = n + bs;
     st.valid = pvalid && b < blk_hi;
     const int64_t bl = b < blk_hi ? b : blk_lo;
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
     st.T0 = (st.s0 * Rt[0] + st.s1 * Rt[1] + st.s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64
     st.T1 = (st.s0 * Rt[3] + st.s1 * Rt[4] + st.s2 * Rt[5]) + tt[1];
     st.T2 = (st.s0 * Rt[6] + st.s1 * Rt[7] + st.s2 * Rt[8]) + tt[2];
-    const double* q = a.table + ((size_t)bl * K + kb) * 3;
+    const double* q = a.tgt + 3 * ti;
     st.q0 = q[0]; st.q1 = q[1]; st.q2 = q[2];
     if (a.corr && st.valid) a.corr[(size_t)p * a.B + b] = kb;
   };
@@ -269,16 +279,21 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
 
   const int64_t n0 = blk_lo + wb * BW;
   if (n0 < blk_hi) {
-    int kb_next = load_kb(n0);
+    // prologue: fill the pipeline (points past the range load harmless clamped addresses)
+    int kb1 = load_kb(n0);
+    int64_t ti1 = load_ti(n0, kb1);
     Stage cur;
-    fetch(n0, kb_next, cur);
-    kb_next = (n0 + STEP < blk_hi) ? load_kb(n0 + STEP) : 0;
+    fetch(n0, ti1, kb1, cur);
+    kb1 = load_kb(n0 + STEP);                 // point n+STEP: byte, then index
+    ti1 = load_ti(n0 + STEP, kb1);
+    int kb2 = load_kb(n0 + 2 * STEP);         // point n+2·STEP: byte
     for (int64_t n = n0; n < blk_hi; n += STEP) {  // wave-uniform
       Stage nxt;
       nxt.valid = false;
-      const bool more = n + STEP < blk_hi;
-      if (more) fetch(n + STEP, kb_next, nxt);
-      if (n + 2 * STEP < blk_hi) kb_next = load_kb(n + 2 * STEP);
+      if (n + STEP < blk_hi) fetch(n + STEP, ti1, kb1, nxt);
+      kb1 = kb2;
+      ti1 = load_ti(n + 2 * STEP, kb1);
+      kb2 = load_kb(n + 3 * STEP);
       finish(cur);
       cur = nxt;
     }

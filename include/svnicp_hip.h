@@ -163,6 +163,8 @@ int svnicp_get_ambiguous_steps(svnicp_ctx *ctx, int *out);
  *   2 k_stein_search_mfma (split stage B only)                 3 k_stein_accumulate* (fused variants: whole stage B)
  *   4 k_reduce_partials                                        5 k_particle_update / k_upd_* */
 #define SVNICP_KERNEL_CLASSES 6
+/* on: 0 = off, 1 = every class, otherwise a mask with bit (class + 1) set for each class to bracket (the event
+ * pairs cost ~5 us of stream time each, so a timed run brackets only what it reports) */
 int svnicp_set_profile(svnicp_ctx *ctx, int on);
 int svnicp_get_kernel_ms(svnicp_ctx *ctx, double *ms6, int32_t *launches6);
 

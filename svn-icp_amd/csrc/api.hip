@@ -85,6 +85,8 @@ struct svnicp_ctx {
   bool timing_valid = false;
   // optional per-kernel-class timing (svnicp_set_profile): event pairs around every launch
   bool profile = false;
+  unsigned profile_mask = 0;            // classes that are bracketed (bit = class index)
+  int pcur = -1;                        // class of the open bracket, -1 = none
   std::vector<hipEvent_t> pev;          // pairs: [2*i] start, [2*i+1] stop
   std::vector<int> pcls;                // kernel class of pair i
   size_t pused = 0;
@@ -106,7 +108,9 @@ constexpr int kFallbackQW = 2;      // … two queries per wave, so a few hundre
 enum { KC_KNN = 0, KC_TABLE = 1, KC_SEARCH = 2, KC_ACCUM = 3, KC_REDUCE = 4, KC_UPDATE = 5, KC_COUNT = SVNICP_KERNEL_CLASSES };
 
 static hipError_t prof_begin(svnicp_ctx* c, int cls) {
-  if (!c->profile) return hipSuccess;
+  c->pcur = -1;
+  if (!c->profile || !((c->profile_mask >> cls) & 1u)) return hipSuccess;
+  c->pcur = cls;
   if (c->pused * 2 + 2 > c->pev.size()) {
     for (int i = 0; i < 2; ++i) {
       hipEvent_t e;
@@ -120,7 +124,8 @@ static hipError_t prof_begin(svnicp_ctx* c, int cls) {
   return hipEventRecord(c->pev[2 * c->pused], c->stream);
 }
 static hipError_t prof_end(svnicp_ctx* c) {
-  if (!c->profile) return hipSuccess;
+  if (!c->profile || c->pcur < 0) return hipSuccess;
+  c->pcur = -1;
   hipError_t r = hipEventRecord(c->pev[2 * c->pused + 1], c->stream);
   c->pused += 1;
   return r;
@@ -693,6 +698,7 @@ int svnicp_get_ambiguous_steps(svnicp_ctx* c, int* out) {
 int svnicp_set_profile(svnicp_ctx* c, int on) {
   CTX_CHECK(c);
   c->profile = on != 0;
+  c->profile_mask = on == 1 ? ~0u : ((unsigned)on >> 1);  // 1 = every class, else bit (class + 1) selects a class
   return SVNICP_OK;
 }
 

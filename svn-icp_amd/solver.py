@@ -223,8 +223,14 @@ class _SolverBase:
     KERNEL_CLASSES = ("stage_a_knn", "k_build_table", "k_stein_search", "k_stein_accumulate", "k_reduce_partials",
                       "k_particle_update")  # include/svnicp_hip.h SVNICP_KERNEL_CLASSES
 
-    def set_profile(self, on: bool):
-        self._check(self._L.svnicp_set_profile(self._h, int(on)), "svnicp_set_profile")
+    def set_profile(self, on, classes=None):
+        """Bracket kernel launches with hipEvents: every class (on=True) or only the named ``classes``."""
+        v = int(bool(on))
+        if on and classes:
+            v = 0
+            for k in classes:
+                v |= 1 << (self.KERNEL_CLASSES.index(k) + 1)
+        self._check(self._L.svnicp_set_profile(self._h, v), "svnicp_set_profile")
 
     def get_kernel_ms(self) -> dict:
         """{kernel class: (total ms in the last align, launches)} — hipEvents on the library's stream."""

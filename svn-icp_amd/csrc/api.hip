@@ -5,6 +5,7 @@
 #include "../../include/svnicp_hip.h"
 
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,7 +61,7 @@ struct svnicp_ctx {
   DevBuf<float> txf, tyf, tzf, cmaxb;
   DevBuf<float4> tablef, tablea;
   DevBuf<uint8_t> kbest;
-  DevBuf<double> sl_d, fail_tau, anchor;
+  DevBuf<double> sl_d, fail_tau, anchor, qrec;
   DevBuf<int32_t> sl_i;
   int sliced_max = 0;  // set at align_begin (kFallbackSlicedMax or SVNICP_FALLBACK_SLICED_MAX)
   DevBuf<int> ambig;
@@ -211,7 +212,7 @@ void svnicp_destroy(svnicp_ctx* c) {
   for (auto* b : dbl) b->release();
   c->eul.release(); c->opt.release(); c->uctl.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
-  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->kbest.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->kbest.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->pev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -365,6 +366,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, c->fail_list.ensure((size_t)B));
     HIPCHK(c, c->fail_count.ensure(1));
     HIPCHK(c, c->fail_tau.ensure((size_t)B));
+    HIPCHK(c, c->qrec.ensure((size_t)B * 6));  // 48-byte records
     HIPCHK(c, c->pool_d.ensure((size_t)kFallbackGrid * 4 * kFallbackQW * c->S));   // fallback rows only
     HIPCHK(c, c->pool_i.ensure((size_t)kFallbackGrid * 4 * kFallbackQW * c->S));
     {
@@ -478,11 +480,38 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
       k.torig = c->torig.p; k.tile_box = c->tile_box.p; k.emax_bits = c->emax.p;
       k.M = c->M; k.Mp = c->Mp; k.n_tiles = (int)(c->Mp / 512); k.b_lo = b_lo; k.b_hi = b_hi; k.K = c->K; k.S2 = c->scan_S2;
       k.pool = c->pool2.p; k.out_idx = c->cand_idx.p; k.out_d2 = c->cand_d2.p;
-      k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p; k.fail_tau = c->fail_tau.p;
+      k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p; k.fail_tau = c->fail_tau.p; k.qrec = c->qrec.p;
       a.qthr = c->fail_tau.p;
       if (c->prm.record_trace) { HIPCHK(c, c->stat_n.ensure((size_t)c->B)); k.stat_n = c->stat_n.p; }
       HIPCHK(c, hipMemsetAsync(c->fail_count.p, 0, sizeof(int), c->stream));
+      static unsigned long long* dbg_phase = nullptr;  // SVNICP_DEBUG: per-phase wave cycles of k_knn_tiles
+      const size_t dbg_waves = (size_t)((n + 255) / 256) * 4;
+      if (getenv("SVNICP_DEBUG")) {
+        if (!dbg_phase) HIPCHK(c, hipMalloc(&dbg_phase, (8 + 8 * 65536) * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(dbg_phase, 0, (8 + 8 * dbg_waves) * sizeof(unsigned long long), c->stream));
+        if (dbg_waves <= 65536) k.phase_cycles = dbg_phase;
+      }
       HIPCHK(c, launch_knn_tiles(k, c->stream));
+      if (k.phase_cycles) {
+        std::vector<unsigned long long> h(8 + 8 * dbg_waves);
+        HIPCHK(c, hipMemcpyAsync(h.data(), dbg_phase, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[svnicp] k_knn_tiles wave cycles: rank %llu seed %llu scan %llu select-rest %llu | select: gather+compact %llu sort %llu output %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+        std::vector<std::pair<unsigned long long, size_t>> tot;
+        for (size_t w = 0; w < dbg_waves; ++w) {
+          unsigned long long t = 0;
+          for (int i = 0; i < 7; ++i) t += h[8 + 8 * w + i];
+          tot.push_back({t, w});
+        }
+        std::sort(tot.begin(), tot.end());
+        auto show = [&](const char* tag, size_t k) {
+          const size_t w = tot[k].second;
+          const unsigned long long* r = &h[8 + 8 * w];
+          fprintf(stderr, "[svnicp]   %s wave %zu: total %llu = rank %llu seed %llu scan %llu gather %llu sort %llu | survivors %llu\n", tag, w,
+                  tot[k].first, r[0], r[1], r[2], r[4], r[5], r[7]);
+        };
+        if (!tot.empty()) { show("median", tot.size() / 2); show("p90   ", tot.size() * 9 / 10); show("p99   ", tot.size() * 99 / 100); show("max   ", tot.size() - 1); }
+      }
       HIPCHK(c, launch_fallback(c, a));
     }
   } else if (c->use_scan) {

@@ -80,6 +80,8 @@ struct KnnTilesArgs {
   int32_t* fail_list;
   int* fail_count;
   int32_t* stat_n;                // optional [B]: survivors of the f32 filter per query (first pass)
+  unsigned long long* phase_cycles;  // optional [8]: summed wave cycles per phase (debug, SVNICP_DEBUG)
+  void* qrec;         // [B] 48-byte per-query records (position, threshold, survivor count) between the two kernels
   double* fail_tau;   // optional [B]: a valid threshold (>= K-th distance) of each failed query, +inf if none
 };
 bool knn_tiles_applicable(int64_t Mp, int K);

@@ -104,6 +104,173 @@ __device__ __forceinline__ float box_lb2(float alo0, float alo1, float alo2, flo
   return (g0 * g0 + g1 * g1 + g2 * g2) * 0.999999f;
 }
 
+// per-query record handed from k_knn_tiles (rank / seed / scan) to k_knn_select
+struct alignas(16) QRec { double x, y, z, tau; int cnt; int row; int pad0, pad1; };
+
+// select: exact f64 distances of the survivors of query position r, keep d² <= tau, order by (d², original
+// index), write the K best to the query's original row.  One wave; sd/si = SL-entry LDS scratch of that wave.
+__device__ void select_query(const KnnTilesArgs& a, int64_t r, const QRec& rec, double* sd, int* si, int lane) {
+  const int K = a.K, S2 = a.S2;
+  const int64_t b = rec.row;
+  const int n_first = rec.cnt;
+  const double qx = rec.x, qy = rec.y, qz = rec.z;
+  double tau = rec.tau;
+  if (a.stat_n && lane == 0) a.stat_n[b] = n_first;
+  const int n = n_first;
+  bool ok = n <= S2;
+  int m = 0;
+  constexpr int NBR = 8;  // survivor batches of 64 held in registers
+  if (ok && n <= NBR * kWave) {
+    // common case: every survivor's slot, then every survivor's coordinates, are requested back to back —
+    // two memory round trips per query instead of two per 64 survivors — and d² stays in registers
+    int slot[NBR], orig[NBR];
+    double d[NBR];
+#pragma unroll
+    for (int j = 0; j < NBR; ++j) {
+      const int e = j * kWave + lane;
+      slot[j] = (j * kWave < n && e < n) ? a.pool[r * (int64_t)S2 + e] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NBR; ++j) {
+      d[j] = __builtin_huge_val(); orig[j] = 0;
+      if (j * kWave < n && slot[j] >= 0) {
+        orig[j] = a.torig[slot[j]];
+        const double dx = qx - a.tx[slot[j]], dy = qy - a.ty[slot[j]], dz = qz - a.tz[slot[j]];
+        d[j] = (dx * dx + dy * dy) + dz * dz;  // knn_cpu.cpp:43-50 order, unfused
+      }
+    }
+    if (n > 2 * kWave && n >= K) {
+      // More survivors than the 128-entry ranking below takes: lower the threshold until between K and 128 of
+      // the register-resident distances pass.  Any such threshold is exact for the top-K; it is found by a
+      // bracketed search on the value (first guess from count ~ d^3, then bisection), a handful of probes of
+      // ballot + popcount each.  Ties that keep more than 128 entries at every threshold leave tau unchanged.
+      auto count_le = [&](double t) -> int {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < NBR; ++j)
+          if (j * kWave < n) c += __popcll(__ballot(slot[j] >= 0 && d[j] <= t));
+        return c;
+      };
+      double lo = 0.0, hi = tau;
+      if (!(hi < __builtin_huge_val())) {  // no finite threshold yet: start from the largest survivor
+        double mx = 0.0;
+#pragma unroll
+        for (int j = 0; j < NBR; ++j) if (slot[j] >= 0) mx = fmax(mx, d[j]);
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, kWave));
+        hi = mx;
+      }
+      const double target = 0.5 * (K + 2 * kWave);
+      double t = hi * (double)__builtin_powf((float)(target / n), 0.6666667f);
+      for (int it = 0; it < 48; ++it) {
+        if (!(t > lo && t < hi)) t = 0.5 * (lo + hi);
+        if (!(t > lo && t < hi)) break;  // bracket exhausted (adjacent doubles)
+        const int c = count_le(t);
+        if (c < K) lo = t;
+        else { hi = t; if (c <= 2 * kWave) break; }
+        t = 0.5 * (lo + hi);
+      }
+      tau = hi < tau ? hi : tau;  // count(d² <= hi) >= K always holds for hi
+    }
+#pragma unroll
+    for (int j = 0; j < NBR; ++j) {
+      if (j * kWave < n) {  // wave-uniform
+        const bool pass = slot[j] >= 0 && d[j] <= tau;
+        const unsigned long long pm = __ballot(pass);
+        const int pos = m + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+        if (pass && pos < SL) { sd[pos] = d[j]; si[pos] = orig[j]; }
+        m += __popcll(pm);
+      }
+    }
+    ok = m >= K && m <= SL;
+  } else if (ok) {
+    if (n > SL / 2) {
+      double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
+      for (int e = lane; e < n; e += kWave) {
+        const int slot = a.pool[r * (int64_t)S2 + e];
+        const double dx = qx - a.tx[slot], dy = qy - a.ty[slot], dz = qz - a.tz[slot];
+        const double d = (dx * dx + dy * dy) + dz * dz;
+        m2 = d < m1 ? m1 : (d < m2 ? d : m2);
+        m1 = d < m1 ? d : m1;
+      }
+      sd[2 * lane] = m1; sd[2 * lane + 1] = m2; si[2 * lane] = 0; si[2 * lane + 1] = 0;
+      wave_sync();
+      bitonic_sort(sd, si, 128, lane);
+      const double t2 = sd[K - 1];
+      wave_sync();
+      tau = t2 < tau ? t2 : tau;
+    }
+    for (int e0 = 0; e0 < n; e0 += kWave) {
+      const int e = e0 + lane;
+      bool pass = false;
+      double d = 0.0;
+      int orig = 0;
+      if (e < n) {
+        const int slot = a.pool[r * (int64_t)S2 + e];
+        orig = a.torig[slot];
+        const double dx = qx - a.tx[slot], dy = qy - a.ty[slot], dz = qz - a.tz[slot];
+        d = (dx * dx + dy * dy) + dz * dz;  // knn_cpu.cpp:43-50 order, unfused
+        pass = d <= tau;
+      }
+      const unsigned long long pm = __ballot(pass);
+      const int pos = m + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+      if (pass && pos < SL) { sd[pos] = d; si[pos] = orig; }
+      m += __popcll(pm);
+    }
+    ok = m >= K && m <= SL;
+  }
+  if (!ok) {
+    if (lane == 0) {
+      const int slot = atomicAdd(a.fail_count, 1);
+      a.fail_list[slot] = (int32_t)b;
+      // tau has K witnesses, so the fallback may start from it; fewer than K survivors means it cannot be trusted
+      if (a.fail_tau) a.fail_tau[slot] = (n <= S2 && m < K) ? __builtin_huge_val() : tau;
+    }
+    wave_sync();
+    return;
+  }
+  if (m <= 2 * kWave) {
+    for (int e = m + lane; e < 2 * kWave + 8; e += kWave) { sd[e] = __builtin_huge_val(); si[e] = 0x7fffffff; }
+    // common case (the bisection above leaves K entries plus exact ties): no sort — every lane ranks its (up to
+    // two) entries against all m by (d², index) with wave-broadcast LDS reads and stores them at their rank
+    wave_sync();
+    const int e0 = lane, e1 = lane + kWave;
+    const double d0 = e0 < m ? sd[e0] : 0.0, d1 = e1 < m ? sd[e1] : 0.0;
+    const int i0 = e0 < m ? si[e0] : 0, i1 = e1 < m ? si[e1] : 0;
+    // rank = #(d_j < d) + #(d_j == d and i_j < i): the first count is compare + add-with-carry per entry (no
+    // scalar mask logic, which is slow behind vector compares on this chip); the second only when ties exist
+    int r0 = 0, r1 = 0, q0c = 0, q1c = 0;
+    for (int j0 = 0; j0 < m; j0 += 8) {  // eight broadcast reads in flight; entries past m are +inf (never less)
+      double dj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dj[u] = sd[j0 + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        r0 += dj[u] < d0 ? 1 : 0; q0c += dj[u] == d0 ? 1 : 0;
+        r1 += dj[u] < d1 ? 1 : 0; q1c += dj[u] == d1 ? 1 : 0;
+      }
+    }
+    if (__ballot((e0 < m && q0c > 1) || (e1 < m && q1c > 1))) {  // exact ties: order them by original index
+      for (int j = 0; j < m; ++j) {
+        const double dj = sd[j];
+        const int ij = si[j];
+        r0 += (dj == d0 && ij < i0) ? 1 : 0;
+        r1 += (dj == d1 && ij < i1) ? 1 : 0;
+      }
+    }
+    if (e0 < m && r0 < K) { a.out_idx[b * K + r0] = i0; a.out_d2[b * K + r0] = d0; }
+    if (e1 < m && r1 < K) { a.out_idx[b * K + r1] = i1; a.out_d2[b * K + r1] = d1; }
+    wave_sync();
+  } else {
+    int S = 256;
+    while (S < m) S <<= 1;
+    for (int e = m + lane; e < S; e += kWave) { sd[e] = __builtin_huge_val(); si[e] = 0x7fffffff; }
+    wave_sync();
+    bitonic_sort(sd, si, S, lane);
+    for (int e = lane; e < K; e += kWave) { a.out_idx[b * K + e] = si[e]; a.out_d2[b * K + e] = sd[e]; }
+    wave_sync();
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -131,6 +298,14 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
   const int nq = (a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW;
   const double Et = __longlong_as_double((long long)*a.emax_bits);
 
+  unsigned long long tphase = a.phase_cycles ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto phase_mark = [&](int i) {  // debug: wave cycles per phase, summed over waves at the end (SVNICP_DEBUG)
+    if (!a.phase_cycles) return;
+    const unsigned long long now = __builtin_readcyclecounter();
+    pacc[i] += now - tphase;
+    tphase = now;
+  };
   // ---- 0. this wave's queries (curve order) and their common box ----
   float wlo0, wlo1, wlo2, whi0, whi1, whi2;
   {
@@ -174,18 +349,34 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
       unsigned long long best[NSQ];
 #pragma unroll
       for (int i = 0; i < NSQ; ++i) best[i] = ~0ull;
-      for (int tile = 0; tile < n_tiles; ++tile) {  // tile boxes are wave-uniform (scalar loads)
-        const float l0 = bx_lo0[tile], l1 = bx_lo1[tile], l2 = bx_lo2[tile], h0 = bx_hi0[tile], h1 = bx_hi1[tile], h2 = bx_hi2[tile];
-        const float lb = box_lb2(px, py, pz, px, py, pz, l0, l1, l2, h0, h1, h2);
-        const float c0 = px - 0.5f * (l0 + h0), c1 = py - 0.5f * (l1 + h1), c2 = pz - 0.5f * (l2 + h2);
-        const float score = lb + 1e-3f * (c0 * c0 + c1 * c1 + c2 * c2);
-        unsigned long long key = (score < __builtin_huge_valf()) ? (((unsigned long long)__float_as_uint(score) << 32) | (unsigned int)tile) : ~0ull;
-#pragma unroll
-        for (int i = 0; i < NSQ; ++i) {  // insertion into the sorted top-NSQ
-          const unsigned long long lo = key < best[i] ? key : best[i];
-          key = key < best[i] ? best[i] : key;
-          best[i] = lo;
+      // 64 tile boxes at a time are fetched lane-per-tile (coalesced) into LDS and then read back as wave
+      // broadcasts: every query scores every tile without a scalar-load round trip per tile
+      float4* boxs = reinterpret_cast<float4*>(scratch);  // [64][2] (the seed buffers are not in use yet)
+      for (int t0 = 0; t0 < n_tiles; t0 += kWave) {
+        const int tl = t0 + lane;
+        if (tl < n_tiles) {
+          boxs[2 * lane] = make_float4(bx_lo0[tl], bx_lo1[tl], bx_lo2[tl], bx_hi0[tl]);
+          boxs[2 * lane + 1] = make_float4(bx_hi1[tl], bx_hi2[tl], 0.f, 0.f);
         }
+        wave_sync();
+        const int cntt = (n_tiles - t0) < kWave ? (n_tiles - t0) : kWave;
+#pragma unroll 4
+        for (int i = 0; i < cntt; ++i) {
+          const float4 b0 = boxs[2 * i], b1 = boxs[2 * i + 1];
+          const float l0 = b0.x, l1 = b0.y, l2 = b0.z, h0 = b0.w, h1 = b1.x, h2 = b1.y;
+          const int tile = t0 + i;
+          const float lb = box_lb2(px, py, pz, px, py, pz, l0, l1, l2, h0, h1, h2);
+          const float c0 = px - 0.5f * (l0 + h0), c1 = py - 0.5f * (l1 + h1), c2 = pz - 0.5f * (l2 + h2);
+          const float score = lb + 1e-3f * (c0 * c0 + c1 * c1 + c2 * c2);
+          unsigned long long key = (score < __builtin_huge_valf()) ? (((unsigned long long)__float_as_uint(score) << 32) | (unsigned int)tile) : ~0ull;
+#pragma unroll
+          for (int u = 0; u < NSQ; ++u) {  // insertion into the sorted top-NSQ
+            const unsigned long long lo = key < best[u] ? key : best[u];
+            key = key < best[u] ? best[u] : key;
+            best[u] = lo;
+          }
+        }
+        wave_sync();
       }
       if (lane < nq) {
 #pragma unroll
@@ -194,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
       }
     }
     wave_sync();
+    phase_mark(0);
     for (int qb0 = 0; qb0 < nq; qb0 += QB) {
       const int nb = (nq - qb0) < QB ? (nq - qb0) : QB;
       for (int e = lane; e < QB * kWave; e += kWave) lm[e] = make_float2(__builtin_huge_valf(), __builtin_huge_valf());
@@ -225,11 +417,17 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
       wave_sync();
       for (int q = 0; q < nb; ++q) {
         const float2 m = lm[q * kWave + lane];
-        sv[2 * lane] = m.x; sv[2 * lane + 1] = m.y;
-        wave_sync();
-        bitonic_sort128_f32(sv, lane);
+        // K-th smallest of the 128 lane minima: bisection on the (non-negative) float bit patterns, 31 probes of
+        // two compares + ballot/popcount instead of a 28-round LDS sort
+        const unsigned int kx = __float_as_uint(m.x), ky = __float_as_uint(m.y);
+        unsigned int kth = 0u;
+        for (int bit = 30; bit >= 0; --bit) {
+          const unsigned int t_try = kth | ((1u << bit) - 1u);  // this bit 0, lower bits 1
+          const int c = __popcll(__ballot(kx <= t_try)) + __popcll(__ballot(ky <= t_try));
+          if (c < K) kth |= 1u << bit;
+        }
         if (lane == 0) {
-          const double tv = (double)sv[K - 1];  // K <= 128 witnesses with f32 distance <= tv
+          const double tv = (double)__uint_as_float(kth);  // K <= 128 witnesses with f32 distance <= tv
           const int qq = qb0 + q;
           const double E = fmax(Et, fmax(fabs(qd[qq].x), fmax(fabs(qd[qq].y), fabs(qd[qq].z))));
           double tau = __builtin_huge_val();
@@ -252,6 +450,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
     }
   }
 
+  phase_mark(1);
   // ---- 2. scan the tiles that can matter ----
   int qcount = 0;
   auto flush = [&]() {
@@ -318,72 +517,37 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
     flush();
   }
 
-  // ---- 3. select: exact f64, keep d2 <= tau, sort by (d2, original index), write to the original row ----
-  for (int q = 0; q < nq; ++q) {
-    const int64_t b = qb[q];
-    const int n_first = __builtin_amdgcn_readfirstlane(cnt[q]);
-    const double qx = qd[q].x, qy = qd[q].y, qz = qd[q].z;
-    double tau = qd[q].tau;
-    if (a.stat_n && lane == 0) a.stat_n[b] = n_first;
-    const int n = n_first;
-    bool ok = n <= S2;
-    int m = 0;
-    if (ok) {
-      if (n > SL / 2) {
-        // Many survivors (the threshold was loose for this query): tighten it from the survivors
-        // themselves.  Two smallest exact distances per lane -> 128 values from distinct targets; their
-        // K-th smallest has K witnesses, so it is a valid (and much tighter) threshold.
-        double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
-        for (int e = lane; e < n; e += kWave) {
-          const int slot = a.pool[(q0 + q) * (int64_t)S2 + e];
-          const double dx = qx - a.tx[slot], dy = qy - a.ty[slot], dz = qz - a.tz[slot];
-          const double d = (dx * dx + dy * dy) + dz * dz;
-          m2 = d < m1 ? m1 : (d < m2 ? d : m2);
-          m1 = d < m1 ? d : m1;
-        }
-        sd[2 * lane] = m1; sd[2 * lane + 1] = m2; si[2 * lane] = 0; si[2 * lane + 1] = 0;
-        wave_sync();
-        bitonic_sort(sd, si, 128, lane);
-        const double t2 = sd[K - 1];
-        wave_sync();
-        tau = t2 < tau ? t2 : tau;
-      }
-      for (int e0 = 0; e0 < n; e0 += kWave) {
-        const int e = e0 + lane;
-        bool pass = false;
-        double d = 0.0;
-        int orig = 0;
-        if (e < n) {
-          const int slot = a.pool[(q0 + q) * (int64_t)S2 + e];
-          orig = a.torig[slot];
-          const double dx = qx - a.tx[slot], dy = qy - a.ty[slot], dz = qz - a.tz[slot];
-          d = (dx * dx + dy * dy) + dz * dz;  // knn_cpu.cpp:43-50 order, unfused
-          pass = d <= tau;
-        }
-        const unsigned long long pm = __ballot(pass);
-        const int pos = m + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
-        if (pass && pos < SL) { sd[pos] = d; si[pos] = orig; }
-        m += __popcll(pm);
-      }
-      ok = m >= K && m <= SL;
-    }
-    if (!ok) {
-      if (lane == 0) {
-        const int slot = atomicAdd(a.fail_count, 1);
-        a.fail_list[slot] = (int32_t)b;
-        // tau has K witnesses, so the fallback may start from it; fewer than K survivors means it cannot be trusted
-        if (a.fail_tau) a.fail_tau[slot] = (n <= S2 && m < K) ? __builtin_huge_val() : tau;
-      }
-      wave_sync();
-      continue;
-    }
-    int S = 128;
-    while (S < m) S <<= 1;
-    for (int e = m + lane; e < S; e += kWave) { sd[e] = __builtin_huge_val(); si[e] = 0x7fffffff; }
-    wave_sync();
-    bitonic_sort(sd, si, S, lane);
-    for (int e = lane; e < K; e += kWave) { a.out_idx[b * K + e] = si[e]; a.out_d2[b * K + e] = sd[e]; }
-    wave_sync();
+  phase_mark(2);
+  // ---- 3. hand over: the select phase runs as its own kernel (one wave per query, all CUs, balanced) ----
+  if (lane < nq) {
+    QRec rec;
+    rec.x = qd[lane].x; rec.y = qd[lane].y; rec.z = qd[lane].z; rec.tau = qd[lane].tau;
+    rec.cnt = cnt[lane]; rec.row = qb[lane]; rec.pad0 = 0; rec.pad1 = 0;
+    reinterpret_cast<QRec*>(a.qrec)[q0 + lane] = rec;
+  }
+  phase_mark(3);
+  if (a.phase_cycles && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.phase_cycles[i], pacc[i]);
+    unsigned long long* pw = a.phase_cycles + 8 + 8 * ((size_t)blockIdx.x * WAVES + wave);  // per-wave record
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pw[i] = pacc[i];
+    int nsum = 0;
+    for (int q = 0; q < nq; ++q) nsum += cnt[q];
+    pw[7] = (unsigned long long)nsum;  // survivors of this wave's queries
+  }
+}
+
+// one wave per query position (grid-stride): see select_query
+__global__ __launch_bounds__(256) void k_knn_select(KnnTilesArgs a) {
+  __shared__ __align__(16) double s_sd[WAVES][SL];
+  __shared__ int s_si[WAVES][SL];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const QRec* recs = reinterpret_cast<const QRec*>(a.qrec);
+  for (int64_t r = a.b_lo + (int64_t)blockIdx.x * WAVES + wave; r < a.b_hi; r += (int64_t)gridDim.x * WAVES) {
+    const QRec rec = recs[r];
+    select_query(a, r, rec, s_sd[wave], s_si[wave], lane);
   }
 }
 
@@ -402,6 +566,11 @@ hipError_t launch_knn_tiles(const KnnTilesArgs& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_knn_tiles, dim3((unsigned)nb), dim3(256), smem, st, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  int64_t nbs = (nq + WAVES - 1) / WAVES;
+  if (nbs > 65536) nbs = 65536;  // grid-stride beyond
+  hipLaunchKernelGGL(k_knn_select, dim3((unsigned)nbs), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

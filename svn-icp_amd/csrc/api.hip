@@ -595,8 +595,20 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
   u.eul = c->eul.p; u.opt = c->opt.p; u.optimizer = c->prm.optimizer; u.n_src = (double)c->B;
   HIPCHK(c, prof_begin(c, KC_UPDATE));
   u.uctl = c->uctl.p;
+  static unsigned long long* dbg_upd = nullptr;  // SVNICP_DEBUG: phase cycles of k_particle_update, printed at finish
+  if (getenv("SVNICP_DEBUG")) {
+    if (!dbg_upd) { HIPCHK(c, hipMalloc(&dbg_upd, 8 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(dbg_upd, 0, 8 * sizeof(unsigned long long))); }
+    u.dbg = dbg_upd;
+    if (it == c->prm.iterations - 1) {
+      unsigned long long h[8];
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpy(h, dbg_upd, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[svnicp] k_particle_update thread-0 cycles (summed over launches so far): prepare %llu median %llu direction %llu pose %llu tail %llu\n", h[0], h[1], h[2], h[3], h[4]);
+    }
+  }
   if (c->prm.mode == SVNICP_MODE_SVGD) HIPCHK(c, launch_update_svgd(u, c->stream));
   else if (c->P > fused_update_max_p()) HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream));
+  else if (c->P >= 2 && !getenv("SVNICP_UPDATE_FUSED")) HIPCHK(c, launch_update_front(u, c->stream));  // A/B switch: fused one-kernel step
   else HIPCHK(c, launch_update(u, c->stream));
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;

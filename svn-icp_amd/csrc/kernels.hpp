@@ -165,13 +165,15 @@ struct UpdateArgs {
   int optimizer;       // SVNICP_OPT_*
   double n_src;        // gradient_scaling_factor_ = B (SVGDICP.cpp:58)
   double* uctl;        // multi-workgroup update path: small control / norm area
+  unsigned long long* dbg;  // optional [8]: cycle stamps of the fused kernel's phases (SVNICP_DEBUG)
 };
 size_t update_workspace_doubles(int P);
 hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose, int mode, double* R, double* t,
                                  double* Rtot, double* pose_out, int refresh_pose, double* eul, hipStream_t st);
 hipError_t launch_update_svgd(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
-hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st);  // P > 256: workgroup-parallel
+hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st);  // P > 128: workgroup-parallel
+hipError_t launch_update_front(const UpdateArgs& a, hipStream_t st);                // 2 <= P <= 128: one-workgroup front + parallel direction
 size_t update_uctl_doubles(int P);
 struct StatsArgs { const double* pose; int P; int mode; double* out; /* mean6,var6,cov36,weightsP */ };
 hipError_t launch_stats(const StatsArgs& a, hipStream_t st);

@@ -183,6 +183,13 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
   __shared__ double sh_Hmean[36];
   __shared__ double sh_norm[UT / kWave];
 
+  unsigned long long tdbg = a.dbg ? __builtin_readcyclecounter() : 0ull;
+  auto stamp = [&](int i) {  // debug (SVNICP_DEBUG): cycles of thread 0 between phase boundaries
+    if (!a.dbg || tid != 0) return;
+    const unsigned long long now = __builtin_readcyclecounter();
+    a.dbg[i] += now - tdbg;
+    tdbg = now;
+  };
   // ---- 1. per particle: H, b, Newton step, x = [t ; Log R] ----
   for (int p = tid; p < P; p += UT) {
     double Rc[9], H[36], b[6], LU[36], x6[6];
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
   }
   sel_init(&sel, P, tid);
   __syncthreads();
+  stamp(0);
 
   if (P > 1) {
     // ---- 2. mean Hessian (SVNICP.cpp:85) and its inverse, RBF bandwidth from the exact median ----
@@ -236,6 +244,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
       for (int r = 0; r < 6; ++r) sh_Hinv[6 * r + lane] = ok ? col[r] : __builtin_nan("");
     }
     rbf_bandwidth(lx, P, w.sq, &sel, tid, lane, wave);
+    stamp(1);
     const double h = sel.h;
     // ---- 4. Stein direction: TPP threads per particle split the sum over j, folded by shuffles;
     //         the pair distance is recomputed from LDS (bit-identical, cheaper than an HBM load) ----
@@ -334,6 +343,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
   }
   __syncthreads();
 
+  stamp(2);
   // ---- 5. traces (tests only) ----
   if (a.trH) {
     for (int e = tid; e < P * 36; e += UT) a.trH[e] = w.H[e];
@@ -378,6 +388,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { a.pose_out[i * P + p] = tn[i]; a.pose_out[(3 + i) * P + p] = lg[i]; }
   }
+  stamp(3);
   bool stop = false;
   if (a.check_early_stop) {  // block-uniform
     for (int off = 32; off > 0; off >>= 1) my_norm += __shfl_xor(my_norm, off, kWave);
@@ -395,6 +406,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
   }
   __syncthreads();
   for (int e = tid; e < 6 * P; e += UT) a.history[(size_t)a.iteration * 6 * P + e] = (float)a.pose_out[e];
+  stamp(4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -645,6 +657,141 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
 #pragma unroll
     for (int r2 = 0; r2 < 6; ++r2) a.uctl[UCTL_HINV + 6 * r2 + lane] = ok ? col[r2] : __builtin_nan("");
   }
+}
+
+// Front half of the Stein step for 2 <= P <= 128 in ONE workgroup (the pair work is small, a launch is not):
+// per-particle H, b, Newton step and x (as k_upd_prepare), mean Hessian inverse, and the exact lower median of
+// the P² pair distances through an LDS copy of the log-binned histogram of the k_upd_* chain: bin the keys,
+// find the median's bin, collect that bin (~0.4 % of the keys), rank its keys by counting.  k_upd_direction
+// (one wavefront per particle, pose update fused) then runs on as many CUs as there are particles.
+// Measured (SVNICP_DEBUG stamps): the 8-pass LDS radix select took 60 % of the fused kernel's 63 us.
+constexpr int FRONT_BUF = 2048;  // keys of the median's bin held in LDS; more (degenerate input) -> 8-pass select
+__global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
+  if (a.ctl[0]) return;
+  extern __shared__ __align__(16) double dyn[];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int P = a.P;
+  Work w(a.work, P);
+  double* lx = dyn;                                                   // [P][6]
+  double* lbuf = dyn + 6 * P;                                         // [FRONT_BUF]
+  unsigned int* lh = reinterpret_cast<unsigned int*>(lbuf + FRONT_BUF);  // [HB_NB]
+  __shared__ SelShared sel;
+  __shared__ double sh_Hmean[36];
+  __shared__ unsigned int sh_scan[UT];
+  __shared__ unsigned int sh_cnt;
+  __shared__ int sh_bin, sh_rank, sh_nan;
+
+  for (int e = tid; e < HB_NB; e += UT) lh[e] = 0u;
+  if (tid == 0) { sh_cnt = 0u; sh_nan = 0; sh_bin = 0; sh_rank = 0; }
+  for (int p = tid; p < P; p += UT) {
+    double Rc[9], H[36], b[6], LU[36], x6[6];
+    int piv[6];
+    mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
+    finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; }
+    const bool ok = lu6(LU, piv);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x6[i] = b[i];
+    lu6_solve(LU, piv, x6);                                   // SVNICP.cpp:162
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { w.b[p * 6 + i] = b[i]; w.N[p * 6 + i] = ok ? x6[i] : __builtin_nan(""); }
+    double lg[3];
+    so3_log(a.R + 9 * p, lg);                                 // SVNICP.cpp:74-77
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      lx[p * 6 + i] = a.t[3 * p + i]; lx[p * 6 + 3 + i] = lg[i];
+      w.x[p * 6 + i] = a.t[3 * p + i]; w.x[p * 6 + 3 + i] = lg[i];
+    }
+  }
+  __syncthreads();  // also makes this workgroup's global writes of H visible to its own reads below
+
+  // mean Hessian (SVNICP.cpp:85) and its inverse (linalg::inv, SVNICP.cpp:225)
+  if (!a.full_grad && tid < 36 * 8) {
+    const int e = tid >> 3, part = tid & 7;
+    double sacc = 0.0;
+    for (int p = part; p < P; p += 8) sacc += w.H[(size_t)p * 36 + e];
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 8);
+    if (part == 0) sh_Hmean[e] = sacc / P;
+  }
+  // pass 1 over the pairs: log-binned histogram
+  const int n = P * P;
+  bool nan = false;
+  for (int e = tid; e < n; e += UT) {
+    const int i = e / P, j = e - i * P;
+    const double sq = pair_sq(lx, i, j);
+    if (sq != sq) nan = true;
+    atomicAdd(&lh[key_bin((unsigned long long)__double_as_longlong(sq))], 1u);
+  }
+  if (nan) sh_nan = 1;
+  __syncthreads();
+  if (!a.full_grad && wave == UT / kWave - 1 && lane < 6) {
+    double LU[36], col[6];
+    int piv[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
+    const bool ok = lu6(LU, piv);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) col[r] = (r == lane) ? 1.0 : 0.0;
+    lu6_solve(LU, piv, col);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a.uctl[UCTL_HINV + 6 * r + lane] = ok ? col[r] : __builtin_nan("");
+  }
+  {  // bin of the lower median: contiguous chunk of bins per thread, block-wide exclusive scan of the chunk sums
+    constexpr int CH = HB_NB / UT;
+    unsigned int c[CH], tot = 0;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { c[i] = lh[tid * CH + i]; tot += c[i]; }
+    sh_scan[tid] = tot;
+    __syncthreads();
+    for (int off = 1; off < UT; off <<= 1) {
+      const unsigned int v = tid >= off ? sh_scan[tid - off] : 0u;
+      __syncthreads();
+      sh_scan[tid] += v;
+      __syncthreads();
+    }
+    unsigned int cum = sh_scan[tid] - tot;
+    const unsigned int rank = (unsigned int)((n - 1) / 2);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (rank >= cum && rank < cum + c[i]) { sh_bin = tid * CH + i; sh_rank = (int)(rank - cum); }
+      cum += c[i];
+    }
+  }
+  __syncthreads();
+  // pass 2: the keys of that bin
+  const int bstar = sh_bin;
+  for (int e = tid; e < n; e += UT) {
+    const int i = e / P, j = e - i * P;
+    const double sq = pair_sq(lx, i, j);
+    if (key_bin((unsigned long long)__double_as_longlong(sq)) == bstar) {
+      const unsigned int pos = atomicAdd(&sh_cnt, 1u);
+      if (pos < FRONT_BUF) lbuf[pos] = sq;
+    }
+  }
+  __syncthreads();
+  const int m = (int)sh_cnt;
+  double med;
+  if (m <= FRONT_BUF) {
+    // exact rank inside the bin by counting: the key with #less <= r < #less + #equal is the median
+    const int r = sh_rank;
+    for (int e = tid; e < m; e += UT) {
+      const double v = lbuf[e];
+      int lt = 0, eq = 0;
+      for (int j = 0; j < m; ++j) { const double u = lbuf[j]; lt += u < v ? 1 : 0; eq += u == v ? 1 : 0; }
+      if (lt <= r && r < lt + eq) sel.h = v;  // every matching thread writes the same value
+    }
+    __syncthreads();
+    med = sel.h;
+  } else {  // degenerate distribution (most pairs in one bin): the general 8-pass select
+    sel_init(&sel, P, tid);
+    __syncthreads();
+    rbf_bandwidth(lx, P, w.sq, &sel, tid, lane, wave);
+    med = sel.h * log((double)(P + 1));  // rbf_bandwidth returns h, undo its scaling
+    __syncthreads();
+  }
+  if (tid == 0) a.uctl[UCTL_H] = (sh_nan ? __builtin_nan("") : med) / log((double)(P + 1));  // SVNICP.cpp:262
 }
 
 // pose update of one particle (SVNICP.cpp:268-279); its step norm goes to uctl[UCTL_NORM + p]
@@ -1080,6 +1227,18 @@ hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st)
   hipLaunchKernelGGL(k_upd_hist, dim3(nb), dim3(256), lds_hist, st, a);
   hipLaunchKernelGGL(k_upd_collect, dim3(nb), dim3(256), lds_coll, st, a);
   hipLaunchKernelGGL(k_upd_select, dim3(1), dim3(UT), lds_sel, st, a);
+  hipLaunchKernelGGL(k_upd_direction, dim3((P + 3) / 4), dim3(256), 0, st, a);
+  if (a.check_early_stop || a.trH) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// 2 <= P <= 128: k_upd_front (one workgroup) -> k_upd_direction (one wavefront per particle) [-> k_upd_finish]
+hipError_t launch_update_front(const UpdateArgs& a, hipStream_t st) {
+  const int P = a.P;
+  const size_t smem = (size_t)P * 6 * sizeof(double) + (size_t)FRONT_BUF * sizeof(double) + (size_t)HB_NB * sizeof(unsigned int);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_front), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_upd_front, dim3(1), dim3(UT), smem, st, a);
   hipLaunchKernelGGL(k_upd_direction, dim3((P + 3) / 4), dim3(256), 0, st, a);
   if (a.check_early_stop || a.trH) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();

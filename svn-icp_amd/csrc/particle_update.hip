@@ -665,7 +665,7 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
 // find the median's bin, collect that bin (~0.4 % of the keys), rank its keys by counting.  k_upd_direction
 // (one wavefront per particle, pose update fused) then runs on as many CUs as there are particles.
 // Measured (SVNICP_DEBUG stamps): the 8-pass LDS radix select took 60 % of the fused kernel's 63 us.
-constexpr int FRONT_BUF = 2048;  // keys of the median's bin held in LDS; more (degenerate input) -> 8-pass select
+constexpr int FRONT_BUF = 2048;  // keys of the median's bin held in LDS (+8 slack for the unrolled ranking); more (degenerate input) -> 8-pass select
 __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
   if (a.ctl[0]) return;
   extern __shared__ __align__(16) double dyn[];
@@ -674,13 +674,49 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
   Work w(a.work, P);
   double* lx = dyn;                                                   // [P][6]
   double* lbuf = dyn + 6 * P;                                         // [FRONT_BUF]
-  unsigned int* lh = reinterpret_cast<unsigned int*>(lbuf + FRONT_BUF);  // [HB_NB]
+  unsigned int* lh = reinterpret_cast<unsigned int*>(lbuf + FRONT_BUF + 8);  // [HB_NB]
   __shared__ SelShared sel;
   __shared__ double sh_Hmean[36];
   __shared__ unsigned int sh_scan[UT];
   __shared__ unsigned int sh_cnt;
   __shared__ int sh_bin, sh_rank, sh_nan;
 
+  if (blockIdx.x == 1) {
+    // second workgroup: mean Hessian (SVNICP.cpp:85) and its inverse (linalg::inv, SVNICP.cpp:225), concurrently
+    // with the median on the first one; the 6x6 LU is a long serial chain that nothing else should wait for
+    if (a.full_grad) return;
+    double* lH = dyn;  // [P][36]
+    for (int p = tid; p < P; p += UT) {
+      double Rc[9], H[36], b[6];
+      mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
+      finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) lH[p * 36 + i] = H[i];
+    }
+    __syncthreads();
+    if (tid < 36 * 8) {
+      const int e = tid >> 3, part = tid & 7;
+      double sacc = 0.0;
+      for (int p = part; p < P; p += 8) sacc += lH[p * 36 + e];
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 8);
+      if (part == 0) sh_Hmean[e] = sacc / P;
+    }
+    __syncthreads();
+    if (tid < 6) {
+      double LU[36], col[6];
+      int piv[6];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
+      const bool ok = lu6(LU, piv);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) col[r] = (r == tid) ? 1.0 : 0.0;
+      lu6_solve(LU, piv, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) a.uctl[UCTL_HINV + 6 * r + tid] = ok ? col[r] : __builtin_nan("");
+    }
+    return;
+  }
   for (int e = tid; e < HB_NB; e += UT) lh[e] = 0u;
   if (tid == 0) { sh_cnt = 0u; sh_nan = 0; sh_bin = 0; sh_rank = 0; }
   for (int p = tid; p < P; p += UT) {
@@ -706,52 +742,45 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
   }
   __syncthreads();  // also makes this workgroup's global writes of H visible to its own reads below
 
-  // mean Hessian (SVNICP.cpp:85) and its inverse (linalg::inv, SVNICP.cpp:225)
-  if (!a.full_grad && tid < 36 * 8) {
-    const int e = tid >> 3, part = tid & 7;
-    double sacc = 0.0;
-    for (int p = part; p < P; p += 8) sacc += w.H[(size_t)p * 36 + e];
-#pragma unroll
-    for (int off = 4; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 8);
-    if (part == 0) sh_Hmean[e] = sacc / P;
-  }
   // pass 1 over the pairs: log-binned histogram
   const int n = P * P;
   bool nan = false;
-  for (int e = tid; e < n; e += UT) {
-    const int i = e / P, j = e - i * P;
-    const double sq = pair_sq(lx, i, j);
-    if (sq != sq) nan = true;
-    atomicAdd(&lh[key_bin((unsigned long long)__double_as_longlong(sq))], 1u);
+  const int di = UT / P, dj = UT - di * P;  // pair index advance per step of UT entries
+  double keys[KREG];                         // this thread's pair distances (P <= 128: KREG * UT >= P²)
+  {
+    int i = tid / P, j = tid - i * P;
+#pragma unroll
+    for (int k = 0; k < KREG; ++k) {
+      const int e = tid + k * UT;
+      keys[k] = __builtin_huge_val();
+      if (e < n) {
+        const double sq = pair_sq(lx, i, j);
+        keys[k] = sq;
+        if (sq != sq) nan = true;
+        atomicAdd(&lh[key_bin((unsigned long long)__double_as_longlong(sq))], 1u);
+      }
+      j += dj; i += di;
+      if (j >= P) { j -= P; ++i; }
+    }
   }
   if (nan) sh_nan = 1;
   __syncthreads();
-  if (!a.full_grad && wave == UT / kWave - 1 && lane < 6) {
-    double LU[36], col[6];
-    int piv[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
-    const bool ok = lu6(LU, piv);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) col[r] = (r == lane) ? 1.0 : 0.0;
-    lu6_solve(LU, piv, col);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) a.uctl[UCTL_HINV + 6 * r + lane] = ok ? col[r] : __builtin_nan("");
-  }
   {  // bin of the lower median: contiguous chunk of bins per thread, block-wide exclusive scan of the chunk sums
     constexpr int CH = HB_NB / UT;
     unsigned int c[CH], tot = 0;
 #pragma unroll
     for (int i = 0; i < CH; ++i) { c[i] = lh[tid * CH + i]; tot += c[i]; }
-    sh_scan[tid] = tot;
-    __syncthreads();
-    for (int off = 1; off < UT; off <<= 1) {
-      const unsigned int v = tid >= off ? sh_scan[tid - off] : 0u;
-      __syncthreads();
-      sh_scan[tid] += v;
-      __syncthreads();
+    unsigned int incl = tot;  // inclusive scan inside the wavefront, then the eight wave totals
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned int v = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += v;
     }
-    unsigned int cum = sh_scan[tid] - tot;
+    if (lane == kWave - 1) sh_scan[wave] = incl;
+    __syncthreads();
+    unsigned int wbase = 0;
+    for (int wv = 0; wv < wave; ++wv) wbase += sh_scan[wv];
+    unsigned int cum = wbase + incl - tot;
     const unsigned int rank = (unsigned int)((n - 1) / 2);
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -762,12 +791,11 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
   __syncthreads();
   // pass 2: the keys of that bin
   const int bstar = sh_bin;
-  for (int e = tid; e < n; e += UT) {
-    const int i = e / P, j = e - i * P;
-    const double sq = pair_sq(lx, i, j);
-    if (key_bin((unsigned long long)__double_as_longlong(sq)) == bstar) {
+#pragma unroll
+  for (int k = 0; k < KREG; ++k) {
+    if (tid + k * UT < n && key_bin((unsigned long long)__double_as_longlong(keys[k])) == bstar) {
       const unsigned int pos = atomicAdd(&sh_cnt, 1u);
-      if (pos < FRONT_BUF) lbuf[pos] = sq;
+      if (pos < FRONT_BUF) lbuf[pos] = keys[k];
     }
   }
   __syncthreads();
@@ -776,10 +804,18 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
   if (m <= FRONT_BUF) {
     // exact rank inside the bin by counting: the key with #less <= r < #less + #equal is the median
     const int r = sh_rank;
+    for (int e = m + tid; e < ((m + 7) & ~7); e += UT) lbuf[e] = __builtin_huge_val();  // pad to the unroll width
+    __syncthreads();
     for (int e = tid; e < m; e += UT) {
       const double v = lbuf[e];
       int lt = 0, eq = 0;
-      for (int j = 0; j < m; ++j) { const double u = lbuf[j]; lt += u < v ? 1 : 0; eq += u == v ? 1 : 0; }
+      for (int j0 = 0; j0 < m; j0 += 8) {  // eight broadcast reads in flight
+        double u[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) u[t] = lbuf[j0 + t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { lt += u[t] < v ? 1 : 0; eq += u[t] == v ? 1 : 0; }
+      }
       if (lt <= r && r < lt + eq) sel.h = v;  // every matching thread writes the same value
     }
     __syncthreads();
@@ -1235,10 +1271,11 @@ hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st)
 // 2 <= P <= 128: k_upd_front (one workgroup) -> k_upd_direction (one wavefront per particle) [-> k_upd_finish]
 hipError_t launch_update_front(const UpdateArgs& a, hipStream_t st) {
   const int P = a.P;
-  const size_t smem = (size_t)P * 6 * sizeof(double) + (size_t)FRONT_BUF * sizeof(double) + (size_t)HB_NB * sizeof(unsigned int);
+  size_t smem = (size_t)P * 6 * sizeof(double) + (size_t)(FRONT_BUF + 8) * sizeof(double) + (size_t)HB_NB * sizeof(unsigned int);
+  if (smem < (size_t)P * 36 * sizeof(double)) smem = (size_t)P * 36 * sizeof(double);  // second workgroup: H of every particle
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_front), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_upd_front, dim3(1), dim3(UT), smem, st, a);
+  hipLaunchKernelGGL(k_upd_front, dim3(2), dim3(UT), smem, st, a);
   hipLaunchKernelGGL(k_upd_direction, dim3((P + 3) / 4), dim3(256), 0, st, a);
   if (a.check_early_stop || a.trH) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();

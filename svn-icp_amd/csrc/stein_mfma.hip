@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NT, 2) void k_stein_accumulate_mfma(AccumArgs a) {
 __global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict__ idx, int64_t B, int K,
                                                       const double* __restrict__ tgt, int64_t M, double* __restrict__ table,
                                                       double* __restrict__ anchor, float4* __restrict__ tablea,
-                                                      float* __restrict__ cmax) {
+                                                      float4* __restrict__ tail, float* __restrict__ cmax) {
   __shared__ float rowbuf[4][128 * 4];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + wave;
@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict_
     anchor[3 * b] = a0; anchor[3 * b + 1] = a1; anchor[3 * b + 2] = a2;
   }
   __builtin_amdgcn_wave_barrier();
+  if (tail && lane < 4) tail[(size_t)b * 4 + lane] = make_float4(rb[4 * (96 + lane)], rb[4 * (96 + lane) + 1], rb[4 * (96 + lane) + 2], rb[4 * (96 + lane) + 3]);
   const int mi = lane & 15, mk = lane >> 4;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -387,10 +388,10 @@ hipError_t launch_accumulate_mfma(const AccumPlan& plan, const AccumArgs& a, hip
 }
 
 hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
-                               double* anchor, float4* tablea, float* cmax, hipStream_t st) {
+                               double* anchor, float4* tablea, float4* tail, float* cmax, hipStream_t st) {
   if (B <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_build_table3, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, idx, B, K, tgt, M, table, anchor, tablea,
-                     cmax);
+                     tail, cmax);
   return hipGetLastError();
 }
 

@@ -38,7 +38,9 @@ __device__ __forceinline__ float imax_f(float a, float b) {
 // ---------------------------------------------------------------------------------------------
 // search: error bound, packing and ambiguity test are those of stein_mfma.hip (see its header)
 // ---------------------------------------------------------------------------------------------
-template <int PW, int WP, int NRB>
+// NRB row blocks of 16 candidates go through the matrix cores; with TAIL the (at most four) candidates 16·NRB …
+// 16·NRB+3 are scored by the VALU in the owner lane instead of spending four mostly empty tiles on them (K = 100)
+template <int PW, int WP, int NRB, bool TAIL>
 __global__ __launch_bounds__(NT, 4) void k_stein_search_mfma(AccumArgs a) {
   if (a.ctl[0]) return;
   constexpr int BW = kWave / PW;   // source points per wave step (1, 2, 4)
@@ -149,6 +151,18 @@ __global__ __launch_bounds__(NT, 4) void k_stein_search_mfma(AccumArgs a) {
       if (mk == cb) { b1own = b1[cb]; b2own = b2[cb]; }
     }
     __builtin_amdgcn_wave_barrier();  // scratch is rewritten by the next step
+    if constexpr (TAIL) {
+      const float4* tl = a.tail + (size_t)bl * 4;
+      const float m0 = -2.0f * xf0, m1 = -2.0f * xf1, m2 = -2.0f * xf2;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 c = tl[t];  // (c'x, c'y, c'z, |c'|²), a finite sentinel past K
+        const float sc = __builtin_fmaf(c.x, m0, __builtin_fmaf(c.y, m1, __builtin_fmaf(c.z, m2, c.w + beta)));
+        const float pk = pack_slot(sc, 0x7fu, (unsigned int)(NRB * 4 + t));  // slot of candidate 16·NRB + t, lane group 0
+        b2own = __builtin_amdgcn_fmed3f(b1own, b2own, pk);
+        b1own = imin_f(b1own, pk);
+      }
+    }
 
     const unsigned int wbits = __float_as_uint(b1own);
     int kb = (int)(((wbits & 0x1cu) << 2) | ((wbits >> 3) & 0xcu) | (wbits & 3u));  // 16·rb + 4·mk + v
@@ -327,21 +341,24 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
   }
 }
 
-inline int row_blocks_for(int K) { return K <= 16 ? 1 : K <= 32 ? 2 : K <= 64 ? 4 : K <= 112 ? 7 : 8; }
+// (row blocks, tail) with an instantiation: K <= 16, 32, 64, 96, 100 (96 + four VALU candidates), 112, 128
+inline int row_code_for(int K) { return K <= 16 ? 1 : K <= 32 ? 2 : K <= 64 ? 4 : K <= 96 ? 6 : K <= 100 ? 60 : K <= 112 ? 7 : 8; }
 
-template <int PW, int WP, int NRB>
+template <int PW, int WP, int NRB, bool TAIL>
 hipError_t launch_s(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((k_stein_search_mfma<PW, WP, NRB>), dim3(plan.sgrid_x, plan.grid_y), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL((k_stein_search_mfma<PW, WP, NRB, TAIL>), dim3(plan.sgrid_x, plan.grid_y), dim3(NT), 0, st, a);
   return hipGetLastError();
 }
 template <int PW, int WP>
 hipError_t launch_srb(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
-  switch (row_blocks_for(a.K)) {
-    case 1: return launch_s<PW, WP, 1>(plan, a, st);
-    case 2: return launch_s<PW, WP, 2>(plan, a, st);
-    case 4: return launch_s<PW, WP, 4>(plan, a, st);
-    case 7: return launch_s<PW, WP, 7>(plan, a, st);
-    default: return launch_s<PW, WP, 8>(plan, a, st);
+  switch (row_code_for(a.K)) {
+    case 1: return launch_s<PW, WP, 1, false>(plan, a, st);
+    case 2: return launch_s<PW, WP, 2, false>(plan, a, st);
+    case 4: return launch_s<PW, WP, 4, false>(plan, a, st);
+    case 6: return launch_s<PW, WP, 6, false>(plan, a, st);
+    case 60: return launch_s<PW, WP, 6, true>(plan, a, st);
+    case 7: return launch_s<PW, WP, 7, false>(plan, a, st);
+    default: return launch_s<PW, WP, 8, false>(plan, a, st);
   }
 }
 template <int PW, int WP>
@@ -354,12 +371,14 @@ template <int PW, int WP>
 void occ_split(int K, size_t smem, int* search, int* accum) {
   int n = 0;
   hipError_t e;
-  switch (row_blocks_for(K)) {
-    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 1>, NT, 0); break;
-    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 2>, NT, 0); break;
-    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 4>, NT, 0); break;
-    case 7: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 7>, NT, 0); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 8>, NT, 0); break;
+  switch (row_code_for(K)) {
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 1, false>, NT, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 2, false>, NT, 0); break;
+    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 4, false>, NT, 0); break;
+    case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 6, false>, NT, 0); break;
+    case 60: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 6, true>, NT, 0); break;
+    case 7: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 7, false>, NT, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_search_mfma<PW, WP, 8, false>, NT, 0); break;
   }
   *search = (e != hipSuccess || n < 1) ? 4 : (n > 8 ? 8 : n);
   n = 0;

@@ -228,7 +228,7 @@ def test_stage_a_fallback_on_pool_overflow(hip, orc, sliced_max, K):
 
 
 @pytest.mark.parametrize("P,full,K", [(70, False, 60), (20, True, 60), (128, False, 100), (9, False, 128), (40, False, 17),
-                                      (33, False, 1)])
+                                      (33, False, 1), (65, False, 80), (17, False, 97), (30, False, 112)])
 def test_stage_b_f32_search_is_bit_identical_to_f64_kernel(hip, P, full, K):
     """stein_iter.hip / stein_mfma.hip: the float32 searches (VALU: SVNICP_ACCUM=valu, matrix cores: default)
     must reproduce the float64 baseline kernel (SVNICP_ACCUM=f64) bit for bit — same correspondences,

@@ -204,7 +204,7 @@ def main():
             out["roofline"] = {"kernel": "k_stein_search_mfma", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF,
                                "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF, "traffic": tr,
                                "note": "f32 MFMA tiles + 3 VALU tracking ops per score share the SIMD issue (PMC in "
-                                       "profiles/): VALU 60 % + MFMA 28 % busy; the HBM view of the same kernel is roofline_hbm; "
+                                       "profiles/): VALU 60 % + MFMA 25 % busy, never co-executing; the HBM view of the same kernel is roofline_hbm; "
                                        "traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/traffic.json)"}
             out["roofline_hbm"] = hbm
         else:

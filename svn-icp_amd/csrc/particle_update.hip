@@ -425,6 +425,7 @@ constexpr int UCTL_H = 2, UCTL_HINV = 3, UCTL_NAN = 40, UCTL_TICKET = 41, UCTL_B
               UCTL_NORM = 64;
 constexpr int HB_OCT = 48, HB_NB = HB_OCT * 256, HB_EXP0 = 1023 - 40;
 constexpr int SEL_LDS_KEYS = 16384;
+constexpr int COLL_CHUNK = 4096;   // pairs per collect chunk = capacity of its LDS staging buffer
 
 __device__ __forceinline__ int key_bin(unsigned long long k) {
   const long long kb = (long long)(k >> 44) - ((long long)HB_EXP0 << 8);
@@ -476,13 +477,11 @@ __global__ __launch_bounds__(128) void k_upd_prepare(UpdateArgs a) {
   }
 }
 
-// pass 1 over all pairs: log-binned histogram (LDS per workgroup, merged with global atomics); the
-// last workgroup to finish scans it for the bin of the lower median
+// pass 1 over all pairs: log-binned histogram (LDS per workgroup, merged with global atomics); the bin of the
+// lower median is found at the start of k_upd_collect (a last-workgroup scan here cost 30 us of serial tail)
 __global__ __launch_bounds__(256) void k_upd_hist(UpdateArgs a) {
   if (a.ctl[0]) return;
   extern __shared__ __align__(16) double dyn[];
-  __shared__ unsigned int sh_scan[256];
-  __shared__ int sh_last;
   const int tid = threadIdx.x;
   const int P = a.P;
   Work w(a.work, P);
@@ -495,11 +494,18 @@ __global__ __launch_bounds__(256) void k_upd_hist(UpdateArgs a) {
   unsigned int* gh = upd_hist(a.uctl, P);
   const int n = P * P;
   bool nan = false;
-  for (int e = blockIdx.x * 256 + tid; e < n; e += gridDim.x * 256) {
-    const int i = e / P, j = e - i * P;
-    const double s = pair_sq(lx, i, j);
-    if (s != s) nan = true;
-    atomicAdd(&lh[key_bin((unsigned long long)__double_as_longlong(s))], 1u);
+  {
+    const int stride = gridDim.x * 256;              // pair index advance per step: (di, dj) without a division per pair
+    const int di = stride / P, dj = stride - di * P;
+    int e = blockIdx.x * 256 + tid;
+    int i = e / P, j = e - i * P;
+    for (; e < n; e += stride) {
+      const double s = pair_sq(lx, i, j);
+      if (s != s) nan = true;
+      atomicAdd(&lh[key_bin((unsigned long long)__double_as_longlong(s))], 1u);
+      j += dj; i += di;
+      if (j >= P) { j -= P; ++i; }
+    }
   }
   if (nan) u[UCTL_NAN] = 1ull;
   __syncthreads();
@@ -507,64 +513,81 @@ __global__ __launch_bounds__(256) void k_upd_hist(UpdateArgs a) {
     const unsigned int c = lh[e];
     if (c) atomicAdd(&gh[e], c);
   }
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) sh_last = (atomicAdd(&u[UCTL_TICKET], 1ull) == (unsigned long long)(gridDim.x - 1));
-  __syncthreads();
-  if (!sh_last) return;
-  __threadfence();
-  constexpr int CH = HB_NB / 256;  // bins per thread, contiguous
-  for (int e = tid; e < HB_NB; e += 256) lh[e] = __hip_atomic_load(&gh[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  unsigned int c[CH], tot = 0;
-#pragma unroll
-  for (int i = 0; i < CH; ++i) { c[i] = lh[tid * CH + i]; tot += c[i]; }
-  sh_scan[tid] = tot;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const unsigned int v = tid >= off ? sh_scan[tid - off] : 0u;
-    __syncthreads();
-    sh_scan[tid] += v;
-    __syncthreads();
-  }
-  unsigned int cum = sh_scan[tid] - tot;
-  const unsigned int rank = (unsigned int)((n - 1) / 2);
-#pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    if (rank >= cum && rank < cum + c[i]) { u[UCTL_BIN] = (unsigned long long)(tid * CH + i); u[UCTL_RANK] = rank - cum; }
-    cum += c[i];
-  }
 }
 
 // pass 2 over all pairs: the keys of the median's bin go to work.sq (LDS staging, one global atomic per workgroup)
 __global__ __launch_bounds__(256) void k_upd_collect(UpdateArgs a) {
   if (a.ctl[0]) return;
   extern __shared__ __align__(16) double dyn[];
-  __shared__ unsigned int sh_cnt;
+  __shared__ unsigned int sh_cnt, sh_wsum[4];
+  __shared__ int sh_bin;
   __shared__ unsigned long long sh_base;
   const int tid = threadIdx.x;
   const int P = a.P;
   Work w(a.work, P);
   double* lx = dyn;
-  double* lbuf = dyn + 6 * P;  // capacity: this workgroup's pair count
+  double* lbuf = dyn + 6 * P;  // [COLL_CHUNK]: matches of one chunk of pairs
   for (int e = tid; e < 6 * P; e += 256) lx[e] = w.x[e];
   if (tid == 0) sh_cnt = 0u;
-  __syncthreads();
   unsigned long long* u = reinterpret_cast<unsigned long long*>(a.uctl);
-  const int bstar = (int)u[UCTL_BIN];
   const int n = P * P;
-  for (int e = blockIdx.x * 256 + tid; e < n; e += gridDim.x * 256) {
-    const int i = e / P, j = e - i * P;
-    const double s = pair_sq(lx, i, j);
-    if (key_bin((unsigned long long)__double_as_longlong(s)) == bstar) lbuf[atomicAdd(&sh_cnt, 1u)] = s;
+  {  // bin of the lower median: every workgroup scans the finished global histogram itself (48 plain loads per
+     // thread, L2 resident); workgroup 0 publishes bin and rank for k_upd_select
+    const unsigned int* gh = upd_hist(a.uctl, P);
+    constexpr int CH = HB_NB / 256;  // bins per thread, contiguous
+    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    unsigned int c[CH], tot = 0;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { c[i] = gh[tid * CH + i]; tot += c[i]; }
+    unsigned int incl = tot;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned int v = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += v;
+    }
+    if (lane == kWave - 1) sh_wsum[wave] = incl;
+    __syncthreads();
+    unsigned int cum = incl - tot;
+    for (int wv = 0; wv < wave; ++wv) cum += sh_wsum[wv];
+    const unsigned int rank = (unsigned int)((n - 1) / 2);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (rank >= cum && rank < cum + c[i]) {
+        sh_bin = tid * CH + i;
+        if (blockIdx.x == 0) { u[UCTL_BIN] = (unsigned long long)(tid * CH + i); u[UCTL_RANK] = rank - cum; }
+      }
+      cum += c[i];
+    }
   }
   __syncthreads();
-  const unsigned int cnt = sh_cnt;
-  if (cnt == 0) return;
-  if (tid == 0) sh_base = atomicAdd(&u[UCTL_CNT], (unsigned long long)cnt);
-  __syncthreads();
-  const unsigned long long base = sh_base;
-  for (unsigned int e = tid; e < cnt; e += 256) w.sq[base + e] = lbuf[e];
+  const int bstar = sh_bin;
+  // the workgroup's pairs in chunks of COLL_CHUNK: a chunk cannot overflow the LDS buffer, and each chunk with
+  // matches costs one global atomic
+  for (int c0 = blockIdx.x * COLL_CHUNK; c0 < n; c0 += gridDim.x * COLL_CHUNK) {
+    const int c1 = (c0 + COLL_CHUNK < n) ? c0 + COLL_CHUNK : n;
+    {
+      const int di = 256 / P, dj = 256 - di * P;
+      int e = c0 + tid;
+      int i = e / P, j = e - i * P;
+      for (; e < c1; e += 256) {
+        const double s = pair_sq(lx, i, j);
+        if (key_bin((unsigned long long)__double_as_longlong(s)) == bstar) lbuf[atomicAdd(&sh_cnt, 1u)] = s;
+        j += dj; i += di;
+        if (j >= P) { j -= P; ++i; }
+      }
+    }
+    __syncthreads();
+    const unsigned int cnt = sh_cnt;
+    if (cnt) {  // block-uniform
+      if (tid == 0) sh_base = atomicAdd(&u[UCTL_CNT], (unsigned long long)cnt);
+      __syncthreads();
+      const unsigned long long base = sh_base;
+      for (unsigned int e = tid; e < cnt; e += 256) w.sq[base + e] = lbuf[e];
+      __syncthreads();
+      if (tid == 0) sh_cnt = 0u;
+      __syncthreads();
+    }
+  }
 }
 
 // generic block-wide exact rank selection over n non-negative f64 keys given by key_at(e); passes above
@@ -615,6 +638,31 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
   Work w(a.work, P);
   __shared__ SelShared sel;
   __shared__ double sh_Hmean[36];
+  if (blockIdx.x == 1) {
+    // second workgroup: mean Hessian from the per-block sums of k_upd_prepare and its inverse (linalg::inv,
+    // SVNICP.cpp:225) — a long serial 6x6 LU that the median select should not wait for
+    if (a.full_grad) return;
+    if (tid < 36) {
+      const double* hp = upd_hpart(a.uctl, P);
+      double sacc = 0.0;
+      for (int q = 0; q < (P + 127) / 128; ++q) sacc += hp[q * 36 + tid];
+      sh_Hmean[tid] = sacc / P;
+    }
+    __syncthreads();
+    if (tid < 6) {
+      double LU[36], col[6];
+      int piv[6];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
+      const bool ok = lu6(LU, piv);
+#pragma unroll
+      for (int r2 = 0; r2 < 6; ++r2) col[r2] = (r2 == tid) ? 1.0 : 0.0;
+      lu6_solve(LU, piv, col);
+#pragma unroll
+      for (int r2 = 0; r2 < 6; ++r2) a.uctl[UCTL_HINV + 6 * r2 + tid] = ok ? col[r2] : __builtin_nan("");
+    }
+    return;
+  }
   const unsigned long long* u = reinterpret_cast<const unsigned long long*>(a.uctl);
   const int m = (int)u[UCTL_CNT];
   const unsigned int r = (unsigned int)u[UCTL_RANK];
@@ -634,28 +682,9 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
     auto key_at = [&](int e) -> unsigned long long { return (unsigned long long)__double_as_longlong(w.sq[e]); };
     kmed = block_select(key_at, m, r, first_pass, prefix0, &sel, tid, lane, wave);
   }
-  if (!a.full_grad && tid < 36) {
-    const double* hp = upd_hpart(a.uctl, P);
-    double s = 0.0;
-    for (int q = 0; q < (P + 127) / 128; ++q) s += hp[q * 36 + tid];
-    sh_Hmean[tid] = s / P;
-  }
-  __syncthreads();
   if (tid == 0) {
     const double med = u[UCTL_NAN] ? __builtin_nan("") : __longlong_as_double((long long)kmed);
     a.uctl[UCTL_H] = med / log((double)(P + 1));              // SVNICP.cpp:262
-  }
-  if (!a.full_grad && wave == 1 && lane < 6) {                // linalg::inv (SVNICP.cpp:225)
-    double LU[36], col[6];
-    int piv[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
-    const bool ok = lu6(LU, piv);
-#pragma unroll
-    for (int r2 = 0; r2 < 6; ++r2) col[r2] = (r2 == lane) ? 1.0 : 0.0;
-    lu6_solve(LU, piv, col);
-#pragma unroll
-    for (int r2 = 0; r2 < 6; ++r2) a.uctl[UCTL_HINV + 6 * r2 + lane] = ok ? col[r2] : __builtin_nan("");
   }
 }
 
@@ -1245,12 +1274,12 @@ hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st)
   const int P = a.P;
   const size_t n = (size_t)P * P;
   const size_t xs = (size_t)P * 6 * sizeof(double);
+  // few, fat workgroups: each one merges its LDS histogram into the global one with atomics, and those contend
   int nb = (int)((n + 1023) / 1024);
-  if (nb > num_cus) nb = num_cus;
+  if (nb > num_cus / 2) nb = num_cus / 2;
   if (nb < 1) nb = 1;
-  const size_t per_block = ((n + (size_t)nb * 256 - 1) / ((size_t)nb * 256)) * 256;  // pairs one workgroup visits (upper bound)
   const size_t lds_hist = xs + (size_t)HB_NB * sizeof(unsigned int);
-  const size_t lds_coll = xs + per_block * sizeof(double);
+  const size_t lds_coll = xs + (size_t)COLL_CHUNK * sizeof(double);
   const size_t lds_sel = (size_t)SEL_LDS_KEYS * sizeof(double);
   if (lds_hist > 150 * 1024 || lds_coll > 150 * 1024) return hipErrorInvalidValue;  // P > ~2000 on a 256-CU part
   {  // raise the dynamic-LDS cap (per device; a cheap host-side call)
@@ -1262,7 +1291,7 @@ hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st)
   hipLaunchKernelGGL(k_upd_prepare, dim3((P + 127) / 128), dim3(128), 0, st, a);
   hipLaunchKernelGGL(k_upd_hist, dim3(nb), dim3(256), lds_hist, st, a);
   hipLaunchKernelGGL(k_upd_collect, dim3(nb), dim3(256), lds_coll, st, a);
-  hipLaunchKernelGGL(k_upd_select, dim3(1), dim3(UT), lds_sel, st, a);
+  hipLaunchKernelGGL(k_upd_select, dim3(2), dim3(UT), lds_sel, st, a);
   hipLaunchKernelGGL(k_upd_direction, dim3((P + 3) / 4), dim3(256), 0, st, a);
   if (a.check_early_stop || a.trH) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();

@@ -117,7 +117,7 @@ def _all_gather_rows(dist, group, full, lo, hi, world, rank):
     n = full.shape[0]
     per = (n + world - 1) // world
     if n == per * world:
-        dist.all_gather_into_tensor(full, full[lo:hi].clone() if full.device.type == "cpu" else full[lo:hi], group=group)
+        dist.all_gather_into_tensor(full, full[lo:hi].clone(), group=group)  # the clone keeps input and output disjoint
         return
     # ragged tail: gather padded blocks, then scatter the valid rows back
     pad = torch.zeros((per,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)

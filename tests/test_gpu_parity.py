@@ -444,6 +444,25 @@ def test_c2_full_parity(hip, orc):
     assert np.allclose(s.get_cov_matrix(), o.get_cov_matrix(), atol=1e-9)
 
 
+@pytest.mark.parametrize("wl,Bs,iters", [("C3", 4096, 20), ("C4", 1536, 8), ("C5", 2048, 6)])
+def test_headline_configs_reduced_source_full_parity(hip, orc, wl, Bs, iters):
+    """BASELINE configs C3 / C4 / C5 with their real particle count, K, target cloud and (for C3) iteration
+    count, on an evenly spaced subset of the source scan so that the CPU oracle finishes in seconds: candidate
+    lists and dist² bit-exact, per-iteration correspondences bit-exact, H/b/step to the trace tolerances, pose,
+    covariance and particles to 1e-9.  C4 exercises the workgroup-parallel Stein update (512 particles), C5 the
+    2 M-point target (4096 Morton tiles, sliced fallback)."""
+    cfg = hip.scans.CONFIGS[wl]
+    pair = hip.scans.make_pair(cfg["B"], cfg["M"])
+    rows = np.linspace(0, cfg["B"] - 1, Bs).astype(np.int64)
+    src = np.ascontiguousarray(pair.source[rows])
+    init = hip.scans.make_particles(cfg["P"])
+    c = dict(iterations=iters, lr=1.0, max_dist=1.0, knn_count=100, svn_full_grad=False)
+    o = orc.Solver(init, **c); o.add_cloud(src, pair.target, init); tro = o.enable_trace(); o.stein_align()
+    s = _hip_solver(hip, init, **c); s.add_cloud(src, pair.target, init)
+    assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+    _compare(s, o, tro, cfg["P"])
+
+
 def test_c3_headline_properties(hip, orc):
     """Headline config C3 at full size through size-independent properties: (a) a random sample of
     candidate rows equals the oracle's brute force on those rows bit-for-bit, (b) every row is

@@ -10,6 +10,7 @@ library or a gfx950 device is missing — there is no CPU fallback.
 from .binding import (SvnIcpError, abi_version, library_path, load_library, declared_symbols)  # noqa: F401
 from .solver import SVNICP, SVGDICP, SteinICPParam, SteinICPState, ParticleWeightOpt, initialize_particles  # noqa: F401
 from . import scans  # noqa: F401
+from . import pipeline, stein_msgs  # noqa: F401  (caller glue and wire formats, SURVEY.md §8(f)-1,2)
 
 __all__ = ["SVNICP", "SVGDICP", "SteinICPParam", "SteinICPState", "ParticleWeightOpt", "initialize_particles",
-           "SvnIcpError", "abi_version", "library_path", "load_library", "declared_symbols", "scans"]
+           "SvnIcpError", "abi_version", "library_path", "load_library", "declared_symbols", "scans", "pipeline", "stein_msgs"]

@@ -293,9 +293,10 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
   double* sd = reinterpret_cast<double*>(scratch);                 // select: [SL]
   int* si = reinterpret_cast<int*>(scratch + sizeof(double) * (size_t)SL);
 
-  const int64_t q0 = a.b_lo + ((int64_t)blockIdx.x * WAVES + wave) * QW;
-  if (q0 >= a.b_hi) return;  // no block-level barriers in this kernel
-  const int nq = (a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW;
+  const int64_t q0blk = a.b_lo + (int64_t)blockIdx.x * WAVES * QW;  // first query position of the workgroup
+  const int64_t q0 = q0blk + (int64_t)wave * QW;
+  // a wave past the end keeps running with no queries: the scan phase below is shared by the workgroup's waves
+  const int nq = q0 >= a.b_hi ? 0 : ((a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW);
   const double Et = __longlong_as_double((long long)*a.emax_bits);
 
   unsigned long long tphase = a.phase_cycles ? __builtin_readcyclecounter() : 0ull;
@@ -451,71 +452,112 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
   }
 
   phase_mark(1);
-  // ---- 2. scan the tiles that can matter ----
+  // ---- 2. scan the tiles that can matter — shared by the workgroup ----
+  // Each wave takes every fourth tile and scores it for the queries of ALL four waves (their records stay in the
+  // owners' LDS regions).  One wave's queries can need several times the median work (loose thresholds); spread
+  // over four waves the slowest workgroup, which sets the kernel time, is much closer to the average.
+  __shared__ float s_gbox[WAVES][8];  // per wave: query box lo xyz, hi xyz, largest box-test threshold, query count
+  {
+    float tmax = thrb[lane];  // -1 for inactive lanes
+    for (int off = 32; off > 0; off >>= 1) tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, off, kWave));
+    if (lane == 0) {
+      s_gbox[wave][0] = wlo0; s_gbox[wave][1] = wlo1; s_gbox[wave][2] = wlo2;
+      s_gbox[wave][3] = whi0; s_gbox[wave][4] = whi1; s_gbox[wave][5] = whi2;
+      s_gbox[wave][6] = nq > 0 ? tmax : -1.0f; s_gbox[wave][7] = __int_as_float(nq);
+    }
+  }
+  __syncthreads();
+  auto grp_qf = [&](int g) { return reinterpret_cast<QF*>(smem + per_wave * g + sizeof(QD) * QW); };
+  auto grp_cnt = [&](int g) { return reinterpret_cast<int*>(smem + per_wave * g + (sizeof(QD) + sizeof(QF)) * QW); };
+  auto grp_thrb = [&](int g) { return reinterpret_cast<float*>(smem + per_wave * g + (sizeof(QD) + sizeof(QF)) * QW + 2 * sizeof(int) * QW); };
   int qcount = 0;
   auto flush = [&]() {
     wave_sync();
     for (int e = lane; e < qcount; e += kWave) {
       const int2 ent = queue[e];
-      const int pos = atomicAdd(&cnt[ent.y], 1);
-      if (pos < S2) a.pool[(q0 + ent.y) * (int64_t)S2 + pos] = ent.x;
+      const int g = ent.y >> 6, q = ent.y & (QW - 1);
+      const int pos = atomicAdd(&grp_cnt(g)[q], 1);
+      if (pos < S2) a.pool[(q0blk + (int64_t)g * QW + q) * (int64_t)S2 + pos] = ent.x;
     }
     qcount = 0;
     wave_sync();
   };
   {
-    float tmax = thrb[lane];  // -1 for inactive lanes
-    for (int off = 32; off > 0; off >>= 1) tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, off, kWave));
-    const float myx = qf[lane].x, myy = qf[lane].y, myz = qf[lane].z, mytb = thrb[lane];
+    float gx[WAVES], gy[WAVES], gz[WAVES], gtb[WAVES];  // lane's query of each group, and its box-test threshold
+    int gnq[WAVES];
+#pragma unroll
+    for (int g = 0; g < WAVES; ++g) {
+      const QF f = grp_qf(g)[lane];
+      gx[g] = f.x; gy[g] = f.y; gz[g] = f.z; gtb[g] = grp_thrb(g)[lane];
+      gnq[g] = __float_as_int(s_gbox[g][7]);
+    }
+    const unsigned long long own = 0x1111111111111111ull << wave;  // tiles t with t % 4 == wave (t0 is a multiple of 64)
     for (int t0 = 0; t0 < n_tiles; t0 += kWave) {
       const int tl = t0 + lane;
-      bool need = false;
-      if (tl < n_tiles)
-        need = box_lb2(wlo0, wlo1, wlo2, whi0, whi1, whi2, bx_lo0[tl], bx_lo1[tl], bx_lo2[tl], bx_hi0[tl], bx_hi1[tl],
-                       bx_hi2[tl]) <= tmax;
-      unsigned long long tmask = __ballot(need);
-      while (tmask) {
-        const int tile = t0 + (int)__builtin_ctzll(tmask);
-        tmask &= tmask - 1;
+      unsigned long long gmask[WAVES];
+      unsigned long long any = 0ull;
+#pragma unroll
+      for (int g = 0; g < WAVES; ++g) {
+        bool need = false;
+        if (tl < n_tiles)
+          need = box_lb2(s_gbox[g][0], s_gbox[g][1], s_gbox[g][2], s_gbox[g][3], s_gbox[g][4], s_gbox[g][5], bx_lo0[tl], bx_lo1[tl],
+                         bx_lo2[tl], bx_hi0[tl], bx_hi1[tl], bx_hi2[tl]) <= s_gbox[g][6];
+        gmask[g] = __ballot(need) & own;
+        any |= gmask[g];
+      }
+      while (any) {
+        const int bit = (int)__builtin_ctzll(any);
+        any &= any - 1;
+        const int tile = t0 + bit;
         const float l0 = bx_lo0[tile], l1 = bx_lo1[tile], l2 = bx_lo2[tile], h0 = bx_hi0[tile], h1 = bx_hi1[tile], h2 = bx_hi2[tile];
-        unsigned long long qmask = __ballot(lane < nq && box_lb2(myx, myy, myz, myx, myy, myz, l0, l1, l2, h0, h1, h2) <= mytb);
-        if (!qmask) continue;
         const int64_t tb = (int64_t)tile * STEP;
         float x[T], y[T], z[T];
+        bool loaded = false;
 #pragma unroll
-        for (int t = 0; t < T; ++t) { x[t] = a.txf[tb + t * kWave + lane]; y[t] = a.tyf[tb + t * kWave + lane]; z[t] = a.tzf[tb + t * kWave + lane]; }
-        while (qmask) {
-          const int q = (int)__builtin_ctzll(qmask);
-          qmask &= qmask - 1;
-          const float4 cur = *reinterpret_cast<const float4*>(&qf[q]);
-          float d[T];
+        for (int g = 0; g < WAVES; ++g) {
+          if (!((gmask[g] >> bit) & 1ull)) continue;  // wave-uniform
+          unsigned long long qmask = __ballot(lane < gnq[g] && box_lb2(gx[g], gy[g], gz[g], gx[g], gy[g], gz[g], l0, l1, l2, h0, h1, h2) <= gtb[g]);
+          if (!qmask) continue;
+          if (!loaded) {
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            const float dx = cur.x - x[t], dy = cur.y - y[t], dz = cur.z - z[t];
-            d[t] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            for (int t = 0; t < T; ++t) { x[t] = a.txf[tb + t * kWave + lane]; y[t] = a.tyf[tb + t * kWave + lane]; z[t] = a.tzf[tb + t * kWave + lane]; }
+            loaded = true;
           }
-          float dm = __builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]);
-#pragma unroll
-          for (int t = 3; t + 1 < T; t += 2) dm = __builtin_fminf(__builtin_fminf(dm, d[t]), d[t + 1]);
-          if constexpr ((T - 3) % 2 == 1) dm = __builtin_fminf(dm, d[T - 1]);
-          if (__ballot(dm <= cur.w)) {
+          const QF* gqf = grp_qf(g);
+          while (qmask) {
+            const int q = (int)__builtin_ctzll(qmask);
+            qmask &= qmask - 1;
+            const float4 cur = *reinterpret_cast<const float4*>(&gqf[q]);
+            float d[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-              const unsigned long long m = __ballot(d[t] <= cur.w);
-              if (m) {
-                const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                if ((m >> lane) & 1ull) queue[pos] = make_int2((int)(tb + t * kWave + lane), q);
-                qcount += __popcll(m);
-              }
+              const float dx = cur.x - x[t], dy = cur.y - y[t], dz = cur.z - z[t];
+              d[t] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
             }
-            qcount = __builtin_amdgcn_readfirstlane(qcount);
-            if (qcount > QCAP - STEP) flush();
+            float dm = __builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]);
+#pragma unroll
+            for (int t = 3; t + 1 < T; t += 2) dm = __builtin_fminf(__builtin_fminf(dm, d[t]), d[t + 1]);
+            if constexpr ((T - 3) % 2 == 1) dm = __builtin_fminf(dm, d[T - 1]);
+            if (__ballot(dm <= cur.w)) {
+#pragma unroll
+              for (int t = 0; t < T; ++t) {
+                const unsigned long long m = __ballot(d[t] <= cur.w);
+                if (m) {
+                  const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                  if ((m >> lane) & 1ull) queue[pos] = make_int2((int)(tb + t * kWave + lane), g * 64 + q);
+                  qcount += __popcll(m);
+                }
+              }
+              qcount = __builtin_amdgcn_readfirstlane(qcount);
+              if (qcount > QCAP - STEP) flush();
+            }
           }
         }
       }
     }
     flush();
   }
+  __syncthreads();  // every wave's survivors are counted before the owners publish their records
 
   phase_mark(2);
   // ---- 3. hand over: the select phase runs as its own kernel (one wave per query, all CUs, balanced) ----

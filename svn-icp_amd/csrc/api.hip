@@ -361,7 +361,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (ensure_target_layout(c)) return c->err.empty() ? SVNICP_ERR_HIP : SVNICP_ERR_HIP;
   if (c->knn_variant != 0) {
-    if (c->knn_variant == 2) c->scan_S2 = 2048;  // deep global pool; the select phase tightens before it sorts
+    if (c->knn_variant == 2) c->scan_S2 = 8192;  // deep global pool (32 KB per query: 288 GB HBM); the select phase tightens before it ranks
     HIPCHK(c, c->pool2.ensure((size_t)B * c->scan_S2));
     HIPCHK(c, c->fail_list.ensure((size_t)B));
     HIPCHK(c, c->fail_count.ensure(1));

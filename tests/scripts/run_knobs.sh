@@ -4,8 +4,9 @@ w=${1:-C3}
 run() { echo "== $*" >> gpurun_out/knobs.log; env "$@" SVNICP_DEBUG=1 timeout -k 10 200 python tests/gpu_time_knn.py $w 2>&1 | grep -E "stage-B plan|stage_a" | tail -2 >> gpurun_out/knobs.log; }
 : > gpurun_out/knobs.log
 run X=0
-run SVNICP_WGPCU=4,3
-run SVNICP_WGPCU=5,4
 run SVNICP_WGPCU=10,4
-run SVNICP_WGPCU=5,8
-run SVNICP_WGPCU=15,12
+run SVNICP_WGPCU=10,2
+run SVNICP_WGPCU=10,6
+run SVNICP_WGPCU=8,3
+run SVNICP_WGPCU=12,3
+run SVNICP_WGPCU=15,3

@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, help="C1|C2|C3|C4|C5 (default: C3; N>1: C3 clouds, 128 particles per GPU)")
     ap.add_argument("--full-grad", type=int, default=0, help="SVNFullGrad (shipped default false)")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="source points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="source points of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent brackets")
     return ap.parse_args()
 

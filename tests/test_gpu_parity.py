@@ -463,6 +463,54 @@ def test_headline_configs_reduced_source_full_parity(hip, orc, wl, Bs, iters):
     _compare(s, o, tro, cfg["P"])
 
 
+def _fuzz_cloud(kind, rng, B, M):
+    """Point sets built to stress the float32 searches: exact ties, duplicates, huge offsets, tiny scales."""
+    if kind == "grid":        # integer lattice: exact ties everywhere
+        tgt = rng.integers(-6, 7, size=(M, 3)).astype(np.float64) * 0.25
+        src = rng.integers(-6, 7, size=(B, 3)).astype(np.float64) * 0.25 + rng.choice([0.0, 0.125], size=(B, 1))
+    elif kind == "dups":      # few distinct targets, many copies
+        base = rng.normal(size=(max(8, M // 50), 3))
+        tgt = base[rng.integers(0, base.shape[0], M)]
+        src = base[rng.integers(0, base.shape[0], B)] + rng.normal(size=(B, 3)) * 0.05
+    elif kind == "far":       # UTM-like coordinates: the error bounds scale with |coordinate|
+        off = np.array([4.5e5, -3.2e5, 1.2e3])
+        tgt = rng.normal(size=(M, 3)) * 3 + off
+        src = tgt[rng.integers(0, M, B)] + rng.normal(size=(B, 3)) * 0.05
+    elif kind == "tiny":      # millimetre-scale cloud
+        tgt = rng.normal(size=(M, 3)) * 1e-3
+        src = tgt[rng.integers(0, M, B)] + rng.normal(size=(B, 3)) * 2e-5
+    else:                     # thin plane + line: strongly anisotropic neighbourhoods
+        tgt = np.concatenate([np.c_[rng.uniform(-5, 5, (M // 2, 2)), rng.normal(size=M // 2) * 1e-4],
+                              np.c_[rng.uniform(-5, 5, M - M // 2), np.zeros(M - M // 2), np.full(M - M // 2, 0.3)]])
+        src = tgt[rng.integers(0, M, B)] + rng.normal(size=(B, 3)) * 0.02
+    return (src.astype(np.float32).astype(np.float64) if kind != "far" else src), tgt
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_searches_stay_exact(hip, orc, seed):
+    """Randomised structure / size / K / particle count: candidate lists bit-exact and the first iteration's
+    correspondences bit-exact for every (particle, point) — the float32 MFMA search with its ambiguity test must
+    never mis-pick.  Later iterations are not compared here: several of these clouds are deliberately
+    ill-conditioned (UTM-sized coordinates, millimetre scale, a handful of distinct points), so a last-bit
+    difference in the summation order legitimately moves the poses, and with them the later correspondences."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["grid", "dups", "far", "tiny", "aniso"][seed % 5]
+    B, M = int(rng.integers(200, 1500)), int(rng.integers(600, 9000))
+    K = int(rng.choice([1, 5, 16, 17, 50, 96, 97, 100, 128]))
+    P = int(rng.choice([2, 9, 16, 33, 64, 96, 130]))
+    src, tgt = _fuzz_cloud(kind, rng, B, M)
+    scale = 1e-3 if kind == "tiny" else 1.0
+    init = hip.scans.make_particles(P, seed=seed + 1) * (0.2 * scale)
+    init[:3] *= 1.0
+    cfg = dict(iterations=1, lr=1.0, max_dist=(1.0 if kind != "tiny" else 1e-6), knn_count=min(K, 128), svn_full_grad=bool(seed & 1))
+    o = orc.Solver(init, **cfg); o.add_cloud(src, tgt, init); tro = o.enable_trace(); o.stein_align()
+    s = _hip_solver(hip, init, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+    assert np.array_equal(s.get_candidates().astype(np.int64), o.candidates()), kind
+    assert np.array_equal(s.get_candidate_dist2(), o.candidate_dist2()), kind
+    assert np.array_equal(s.get_trace()["corr"][:1], tro["corr"][:1]), kind
+    assert np.allclose(s.get_trace()["H"][:1], tro["H"][:1], rtol=1e-9, atol=1e-9 * scale * scale), kind
+
+
 def test_c3_headline_properties(hip, orc):
     """Headline config C3 at full size through size-independent properties: (a) a random sample of
     candidate rows equals the oracle's brute force on those rows bit-for-bit, (b) every row is

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
 
   // four-stage pipeline: winner byte of point n+3·STEP | its target index (n+2·STEP) | winner coordinates and Ts
   // (n+STEP) | sums of n — every load has a full step of other work between issue and use
-  struct Stage { double s0, s1, s2, T0, T1, T2, q0, q1, q2; bool valid; };
+  struct Stage { double s0, s1, s2, q0, q1, q2; bool valid; };  // raw loads only: nothing in fetch waits for memory
   auto load_kb = [&](int64_t n) -> int {
     const int64_t b = n + bs;
     return (pvalid && b < blk_hi) ? (int)a.kbest[(size_t)b * a.Ppad + pidx] : 0;
@@ -259,16 +259,16 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
     const int64_t bl = b < blk_hi ? b : blk_lo;
     const double* sp = a.src + 3 * bl;
     st.s0 = sp[0]; st.s1 = sp[1]; st.s2 = sp[2];
-    st.T0 = (st.s0 * Rt[0] + st.s1 * Rt[1] + st.s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64
-    st.T1 = (st.s0 * Rt[3] + st.s1 * Rt[4] + st.s2 * Rt[5]) + tt[1];
-    st.T2 = (st.s0 * Rt[6] + st.s1 * Rt[7] + st.s2 * Rt[8]) + tt[2];
     const double* q = a.tgt + 3 * ti;
     st.q0 = q[0]; st.q1 = q[1]; st.q2 = q[2];
     if (a.corr && st.valid) a.corr[(size_t)p * a.B + b] = kb;
   };
   auto finish = [&](const Stage& st) {
     if (!st.valid) return;
-    const double dx = st.T0 - st.q0, dy = st.T1 - st.q1, dz = st.T2 - st.q2;
+    const double T0 = (st.s0 * Rt[0] + st.s1 * Rt[1] + st.s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64
+    const double T1 = (st.s0 * Rt[3] + st.s1 * Rt[4] + st.s2 * Rt[5]) + tt[1];
+    const double T2 = (st.s0 * Rt[6] + st.s1 * Rt[7] + st.s2 * Rt[8]) + tt[2];
+    const double dx = T0 - st.q0, dy = T1 - st.q1, dz = T2 - st.q2;
     const double best = (dx * dx + dy * dy) + dz * dz;   // exact d² of the winner (knn_cpu.cpp:43-50 order)
     double w = 1.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
     if (best < a.max_dist) {  // point_filter, SVGDICP.cpp:331-333
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
     acc[0] += w;
     acc[1] += w0; acc[2] += w1; acc[3] += w2;
     // SVGD mode needs count_nonzero(mask·Ts summed over xyz) (SVGDICP.cpp:404) instead of Σw·s_x²
-    acc[4] = a.svgd ? acc[4] + ((best < a.max_dist && ((st.T0 + st.T1) + st.T2) != 0.0) ? 1.0 : 0.0) : fma(w0, n0, acc[4]);
+    acc[4] = a.svgd ? acc[4] + ((best < a.max_dist && ((T0 + T1) + T2) != 0.0) ? 1.0 : 0.0) : fma(w0, n0, acc[4]);
     acc[5] = fma(w0, n1, acc[5]); acc[6] = fma(w0, n2, acc[6]);
     acc[7] = fma(w1, n1, acc[7]); acc[8] = fma(w1, n2, acc[8]); acc[9] = fma(w2, n2, acc[9]);
     acc[10] += e0; acc[11] += e1; acc[12] += e2;

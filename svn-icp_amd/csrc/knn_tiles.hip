@@ -353,7 +353,37 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
       // 64 tile boxes at a time are fetched lane-per-tile (coalesced) into LDS and then read back as wave
       // broadcasts: every query scores every tile without a scalar-load round trip per tile
       float4* boxs = reinterpret_cast<float4*>(scratch);  // [64][2] (the seed buffers are not in use yet)
-      for (int t0 = 0; t0 < n_tiles; t0 += kWave) {
+      // Groups of 64 consecutive tiles (compact along the curve) are visited nearest first, by the lower bound between
+      // the wave's query box and the group's box, and the visit stops when that bound exceeds every query's current
+      // fourth-best score: no tile of a farther group can enter any top-NSQ list, so the picks equal those of a full
+      // pass — at a cost that no longer grows with the number of tiles (2 M-point targets: 4096 tiles).
+      const int n_groups = (n_tiles + kWave - 1) / kWave;  // <= 128
+      unsigned int gkey[2] = {0xffffffffu, 0xffffffffu};     // lane's groups: bound (7 low mantissa bits cut) | group index
+      for (int g = 0; g < n_groups; ++g) {
+        const int tl = g * kWave + lane;
+        const float inf = __builtin_huge_valf();
+        float lo0 = inf, lo1 = inf, lo2 = inf, hi0 = -inf, hi1 = -inf, hi2 = -inf;
+        if (tl < n_tiles) { lo0 = bx_lo0[tl]; lo1 = bx_lo1[tl]; lo2 = bx_lo2[tl]; hi0 = bx_hi0[tl]; hi1 = bx_hi1[tl]; hi2 = bx_hi2[tl]; }
+        for (int off = 32; off > 0; off >>= 1) {
+          lo0 = __builtin_fminf(lo0, __shfl_xor(lo0, off, kWave)); hi0 = __builtin_fmaxf(hi0, __shfl_xor(hi0, off, kWave));
+          lo1 = __builtin_fminf(lo1, __shfl_xor(lo1, off, kWave)); hi1 = __builtin_fmaxf(hi1, __shfl_xor(hi1, off, kWave));
+          lo2 = __builtin_fminf(lo2, __shfl_xor(lo2, off, kWave)); hi2 = __builtin_fmaxf(hi2, __shfl_xor(hi2, off, kWave));
+        }
+        const float glb = box_lb2(wlo0, wlo1, wlo2, whi0, whi1, whi2, lo0, lo1, lo2, hi0, hi1, hi2);  // empty boxes give +inf or NaN
+        const unsigned int key = (glb < inf) ? ((__float_as_uint(glb) & ~127u) | (unsigned int)g) : 0xffffffffu;
+        if (lane == (g & (kWave - 1))) gkey[g >> 6] = key;
+      }
+      for (;;) {
+        unsigned int kmin = gkey[0] < gkey[1] ? gkey[0] : gkey[1];
+        for (int off = 32; off > 0; off >>= 1) { const unsigned int o = __shfl_xor(kmin, off, kWave); kmin = o < kmin ? o : kmin; }
+        if (kmin == 0xffffffffu) break;
+        float w4 = -__builtin_huge_valf();  // largest fourth-best score among the wave's queries (+inf while a list is not full)
+        if (lane < nq) w4 = best[NSQ - 1] == ~0ull ? __builtin_huge_valf() : __uint_as_float((unsigned int)(best[NSQ - 1] >> 32));
+        for (int off = 32; off > 0; off >>= 1) w4 = __builtin_fmaxf(w4, __shfl_xor(w4, off, kWave));
+        if (__uint_as_float(kmin & ~127u) > w4) break;
+        const int gsel = (int)(kmin & 127u);
+        if (lane == (gsel & (kWave - 1))) gkey[gsel >> 6] = 0xffffffffu;
+        const int t0 = gsel * kWave;
         const int tl = t0 + lane;
         if (tl < n_tiles) {
           boxs[2 * lane] = make_float4(bx_lo0[tl], bx_lo1[tl], bx_lo2[tl], bx_hi0[tl]);

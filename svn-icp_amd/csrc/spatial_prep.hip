@@ -54,13 +54,22 @@ __global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ pts, in
       hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, kWave));
     }
   }
+  // one set of atomics per workgroup (same-address atomics from every wave serialise at L2)
+  __shared__ double s_lo[4][3], s_hi[4][3];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      if (lo[d] <= hi[d]) { atomicMin(&bbox[d], enc_f64(lo[d])); atomicMax(&bbox[3 + d], enc_f64(hi[d])); }
-    }
+    for (int d = 0; d < 3; ++d) { s_lo[wave][d] = lo[d]; s_hi[wave][d] = hi[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int d = threadIdx.x;
+    double l = s_lo[0][d], h = s_hi[0][d];
+    for (int w = 1; w < 4; ++w) { l = fmin(l, s_lo[w][d]); h = fmax(h, s_hi[w][d]); }
+    if (l <= h) { atomicMin(&bbox[d], enc_f64(l)); atomicMax(&bbox[3 + d], enc_f64(h)); }
   }
 }
+
 
 __device__ __forceinline__ unsigned int spread10(unsigned int v) {  // 10 bits -> every third bit
   v &= 0x3ffu;
@@ -181,7 +190,7 @@ hipError_t launch_bbox(const double* pts, int64_t n, unsigned long long* bbox, h
   e = hipMemsetAsync(bbox + 3, 0, 3 * sizeof(unsigned long long), st);
   if (e != hipSuccess) return e;
   int64_t nb = (n + 255) / 256;
-  if (nb > 128) nb = 128;  // grid-stride: few atomics
+  if (nb > 1024) nb = 1024;  // grid-stride; one set of atomics per workgroup
   hipLaunchKernelGGL(k_bbox, dim3((unsigned)nb), dim3(256), 0, st, pts, n, bbox);
   return hipGetLastError();
 }

@@ -150,6 +150,8 @@ int svnicp_get_gpu_ms(svnicp_ctx *ctx, double out3[3]);
 /* number of queries of the last stage A that the pre-filtered kernel handed to the streaming
  * fallback (-1 when the streaming kernel ran alone) */
 int svnicp_get_knn_fallbacks(svnicp_ctx *ctx, int *out);
+/* the source rows behind that count (at most `cap` of them, unordered); *n_out = the count */
+int svnicp_get_knn_fallback_rows(svnicp_ctx *ctx, int32_t *out, int cap, int *n_out);
 /* per source point: how many targets survived the float32 pre-filter of the pruned stage-A kernel
  * (needs params.record_trace) */
 int svnicp_get_knn_survivors(svnicp_ctx *ctx, int32_t *outB);

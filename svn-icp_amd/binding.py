@@ -82,6 +82,7 @@ def load_library():
     L.svnicp_get_trace.argtypes = [vp, ip, dp, dp, dp, dp, dp]
     L.svnicp_get_knn_fallbacks.argtypes = [vp, C.POINTER(C.c_int)]
     L.svnicp_get_knn_survivors.argtypes = [vp, ip]
+    L.svnicp_get_knn_fallback_rows.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_int)]
     L.svnicp_get_ambiguous_steps.argtypes = [vp, C.POINTER(C.c_int)]
     L.svnicp_set_profile.argtypes = [vp, C.c_int]
     L.svnicp_get_kernel_ms.argtypes = [vp, dp, ip]
@@ -98,9 +99,7 @@ def load_library():
     L.svnicp_sums_devptr.argtypes = [vp]
     L.svnicp_sums_devptr.restype = vp
     for name in declared_symbols():
-        fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("svnicp_abi_version",):
-            pass
+        getattr(L, name)  # AttributeError here = the header declares a symbol the library does not export
     _lib = L
     return L
 

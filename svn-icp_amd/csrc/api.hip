@@ -722,6 +722,20 @@ int svnicp_get_knn_fallbacks(svnicp_ctx* c, int* out) {
   return fetch(c, out, c->fail_count.p, sizeof(int));
 }
 
+int svnicp_get_knn_fallback_rows(svnicp_ctx* c, int32_t* out, int cap, int* n_out) {
+  CTX_CHECK(c);
+  if (!c->have_candidates || !n_out) return fail(c, SVNICP_ERR_INVALID, "no candidates yet");
+  *n_out = 0;
+  if (c->knn_variant == 0) return SVNICP_OK;
+  int n = 0;
+  int rc = fetch(c, &n, c->fail_count.p, sizeof(int));
+  if (rc) return rc;
+  *n_out = n;
+  if (n > cap) n = cap;
+  if (n > 0 && out) return fetch(c, out, c->fail_list.p, (size_t)n * 4);
+  return SVNICP_OK;
+}
+
 int svnicp_get_knn_survivors(svnicp_ctx* c, int32_t* outB) {
   CTX_CHECK(c);
   if (!c->have_candidates || c->knn_variant != 2 || !c->prm.record_trace || !c->stat_n.p)

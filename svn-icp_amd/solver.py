@@ -252,6 +252,14 @@ class _SolverBase:
         self._check(self._L.svnicp_get_knn_fallbacks(self._h, C.byref(v)), "svnicp_get_knn_fallbacks")
         return int(v.value)
 
+    def get_knn_fallback_rows(self) -> np.ndarray:
+        """Source rows the pruned stage-A kernel handed to the streaming fallback (unordered)."""
+        n = C.c_int(0)
+        out = np.zeros(max(1, self._B), np.int32)
+        self._check(self._L.svnicp_get_knn_fallback_rows(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size,
+                                                         C.byref(n)), "svnicp_get_knn_fallback_rows")
+        return out[:max(0, min(int(n.value), out.size))].copy()
+
     def get_knn_survivors(self) -> np.ndarray:
         """Per source point: targets that survived the f32 pre-filter of the pruned stage-A kernel (record_trace)."""
         out = np.zeros(self._B, np.int32)

@@ -126,7 +126,8 @@ struct AccumArgs {
   uint8_t* kbest;       // split variant: winner index per (source point, particle of the shard), [B][Ppad]
   int pts_per_block, spts_per_block;  // split variant: source points per workgroup (accumulate / search kernel)
 };
-struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem; };
+struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem;
+                   int search_f32; /* split variant: 1 = f32-input MFMA search kernel (A/B), 0 = bf16x3 matrix pipe (default) */ };
 // f32: 0 = float64 baseline, 1 = float32 VALU search, 2 = float32 MFMA search fused with the accumulation,
 // 3 = MFMA search kernel + accumulation kernel (2 and 3 fall back to 1 when K > 128 or P <= 8)
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32);
@@ -134,7 +135,7 @@ int mfma_occupancy_blocks(int PW, int WP, int K, size_t smem);
 hipError_t launch_accumulate_mfma(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);
 hipError_t launch_search_split(const AccumPlan& plan, AccumArgs a, hipStream_t st);         // split variant, kernel 1
 hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);  // split variant, kernel 2 (via launch_accumulate)
-void split_occupancy_blocks(int PW, int WP, int K, size_t smem, int* search, int* accum);
+void split_occupancy_blocks(int PW, int WP, int K, size_t smem, bool search_f32, int* search, int* accum);
 // table may be nullptr (split variant): then only anchor / tablea / cmax are written
 hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
                                double* anchor, float4* tablea, float4* tail, float* cmax, hipStream_t st);

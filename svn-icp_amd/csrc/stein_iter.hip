@@ -27,6 +27,7 @@
 // cross-lane/wave/block reduction happens once at the end, in a fixed order (deterministic).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.hpp"
 #include "stein_common.hpp"
@@ -460,7 +461,8 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
     };
     pl.smem = (size_t)(WB - 1) * per_wg * kNSums * sizeof(double);
     int occ_s = 4, occ_a = 3;
-    split_occupancy_blocks(PW, WP, K, pl.smem, &occ_s, &occ_a);
+    { const char* e = getenv("SVNICP_SEARCH"); pl.search_f32 = (e && !strcmp(e, "f32")) ? 1 : 0; }  // A/B switch
+    split_occupancy_blocks(PW, WP, K, pl.smem, pl.search_f32 != 0, &occ_s, &occ_a);
     if (const char* e = getenv("SVNICP_WGPCU")) {  // profiling knob: "<search>,<accumulate>" workgroups per CU
       int x = 0, y = 0;
       if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 1 && x <= 16 && y >= 1 && y <= 16) { occ_s = x; occ_a = y; }

@@ -383,6 +383,8 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
                                                           int p_lo, int n_particles, double* __restrict__ sums,
                                                           const int* __restrict__ ctl) {
   if (ctl[0]) return;
+  // 16 entries x 16 block slices per workgroup; every thread sums its blocks in a fixed order with eight loads in
+  // flight, then the 16 slices are added in a fixed order: deterministic, and independent of the launch geometry
   __shared__ double red[16][17];
   const int el = threadIdx.x & 15, bl = threadIdx.x >> 4;
   const int entry = blockIdx.x * 16 + el;  // index into [n_particles][kNSums]
@@ -390,7 +392,16 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
   double a = 0.0;
   if (entry < n_entries) {
     const size_t stride = (size_t)Ppad * kNSums;
-    for (int blk = bl; blk < nblk; blk += 16) a += partial[(size_t)blk * stride + entry];
+    const double* src = partial + entry;
+    int blk = bl;
+    for (; blk + 7 * 16 < nblk; blk += 8 * 16) {
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(blk + 16 * i) * stride];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a += v[i];
+    }
+    for (; blk < nblk; blk += 16) a += src[(size_t)blk * stride];
   }
   red[bl][el] = a;
   __syncthreads();
@@ -468,8 +479,8 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
       if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 1 && x <= 16 && y >= 1 && y <= 16) { occ_s = x; occ_a = y; }
     }
     else {  // measured at C3: the barrier-free search kernel balances best with two rounds of smaller workgroups;
-      occ_s *= 2;                        // the accumulate kernel pays per workgroup in k_reduce_partials: 3 per CU
-      if (occ_a > 3) occ_a = 3;
+      occ_s *= 2;                        // the accumulate kernel pays per workgroup in k_reduce_partials: 4 per CU
+      if (occ_a > 4) occ_a = 4;
     }
     size_grid(occ_a, &pl.grid_x, &pl.pts_per_block);
     size_grid(occ_s, &pl.sgrid_x, &pl.spts_per_block);

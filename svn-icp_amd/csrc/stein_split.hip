@@ -22,6 +22,7 @@ namespace svnicp {
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+#define SVNICP_CONST_AS __attribute__((address_space(4)))   // read-only for the launch: wave-uniform addresses become s_load
 
 __device__ __forceinline__ float pack_slot(float v, unsigned int mask, unsigned int bits) {
   return __uint_as_float((__float_as_uint(v) & ~mask) | bits);
@@ -231,7 +232,6 @@ typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-#define SVNICP_CONST_AS __attribute__((address_space(4)))   // read-only for the launch: wave-uniform addresses become s_load
 
 __device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {  // v_cvt_pk_bf16_f32: RNE, lo in bits 15:0
   const f2v v = {lo, hi};
@@ -560,11 +560,13 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
 // ---------------------------------------------------------------------------------------------
 // accumulation from the winner bytes
 // ---------------------------------------------------------------------------------------------
-template <int PW, int WP>
+// PLAIN: SVN mode without the correspondence trace (the timed configuration): no per-pair branches at all
+template <int PW, int WP, bool PLAIN>
 __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
   if (a.ctl[0]) return;
   constexpr int BW = kWave / PW;
   constexpr int WB = 4 / WP;
+  constexpr int U = 4;             // points per wave and loop trip: their three dependent loads go out as three batches
   extern __shared__ __align__(16) double lds[];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -590,50 +592,41 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
   const int64_t blk_lo = (int64_t)blockIdx.x * a.pts_per_block;
   const int64_t blk_hi = (blk_lo + a.pts_per_block < a.B) ? blk_lo + a.pts_per_block : a.B;
   constexpr int STEP = WB * BW;
+  const SVNICP_CONST_AS double* csrc = (const SVNICP_CONST_AS double*)a.src;       // wave-uniform rows become s_load
+  const SVNICP_CONST_AS int32_t* ccand = (const SVNICP_CONST_AS int32_t*)a.cand;
+  const SVNICP_CONST_AS double* ctgt = (const SVNICP_CONST_AS double*)a.tgt;
+  const uint8_t* kbp = a.kbest + pidx;
 
-  // four-stage pipeline: winner byte of point n+3·STEP | its target index (n+2·STEP) | winner coordinates and Ts
-  // (n+STEP) | sums of n — every load has a full step of other work between issue and use
-  struct Stage { double s0, s1, s2, q0, q1, q2; bool valid; };  // raw loads only: nothing in fetch waits for memory
+  // per trip: winner bytes of the NEXT trip's U points | target indices | winner coordinates | sums — each batch of loads
+  // is requested back to back, so a trip pays the byte -> index -> coordinates chain once for U points, and nothing is
+  // carried between trips except the U prefetched bytes (no rotating copies).  Rows are clamped, never predicated: a
+  // point past the block only changes `on`.
   auto load_kb = [&](int64_t n) -> int {
     const int64_t b = n + bs;
-    return (pvalid && b < blk_hi) ? (int)a.kbest[(size_t)b * a.Ppad + pidx] : 0;
+    return (int)kbp[(size_t)(b < blk_hi ? b : blk_lo) * a.Ppad];
   };
-  auto load_ti = [&](int64_t n, int kb) -> int64_t {  // target index of the winner; clamped like k_build_table3
-    const int64_t b = n + bs;
-    const int64_t bl = b < blk_hi ? b : blk_lo;
-    int64_t ti = a.cand[(size_t)bl * K + kb];
-    return ti < 0 ? 0 : (ti >= a.M ? a.M - 1 : ti);
-  };
-  auto fetch = [&](int64_t n, int64_t ti, int kb, Stage& st) {
-    const int64_t b = n + bs;
-    st.valid = pvalid && b < blk_hi;
-    const int64_t bl = b < blk_hi ? b : blk_lo;
-    const double* sp = a.src + 3 * bl;
-    st.s0 = sp[0]; st.s1 = sp[1]; st.s2 = sp[2];
-    const double* q = a.tgt + 3 * ti;
-    st.q0 = q[0]; st.q1 = q[1]; st.q2 = q[2];
-    if (a.corr && st.valid) a.corr[(size_t)p * a.B + b] = kb;
-  };
-  auto finish = [&](const Stage& st) {
-    if (!st.valid) return;
-    const double T0 = (st.s0 * Rt[0] + st.s1 * Rt[1] + st.s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64
-    const double T1 = (st.s0 * Rt[3] + st.s1 * Rt[4] + st.s2 * Rt[5]) + tt[1];
-    const double T2 = (st.s0 * Rt[6] + st.s1 * Rt[7] + st.s2 * Rt[8]) + tt[2];
-    const double dx = T0 - st.q0, dy = T1 - st.q1, dz = T2 - st.q2;
+  // The reference zeroes a rejected row by multiplying with the mask (SVGDICP.cpp:331-333): e = 0, |e| = 0, so w = 1 and
+  // J = [R | 0] — the same products are formed here (mf = 0 or 1), which also makes the pair branch-free.
+  // `on`: 1.0 for a pair that exists, 0.0 for a point past the block (padding particle lanes are never read back).
+  auto accumulate = [&](double on, double s0, double s1, double s2, double q0, double q1, double q2) {
+    const double T0 = (s0 * Rt[0] + s1 * Rt[1] + s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64
+    const double T1 = (s0 * Rt[3] + s1 * Rt[4] + s2 * Rt[5]) + tt[1];
+    const double T2 = (s0 * Rt[6] + s1 * Rt[7] + s2 * Rt[8]) + tt[2];
+    const double dx = T0 - q0, dy = T1 - q1, dz = T2 - q2;
     const double best = (dx * dx + dy * dy) + dz * dz;   // exact d² of the winner (knn_cpu.cpp:43-50 order)
-    double w = 1.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
-    if (best < a.max_dist) {  // point_filter, SVGDICP.cpp:331-333
-      const double nn = sqrt(best);                       // SVNICP.cpp:120
-      const double wq = a.max_dist / (a.max_dist + 3 * nn);
-      w = wq * wq;                                        // SVNICP.cpp:122
-      e0 = w * dx; e1 = w * dy; e2 = w * dz;              // SVNICP.cpp:119,123
-      n0 = st.s0; n1 = st.s1; n2 = st.s2;
-    }
+    const double mf = best < a.max_dist ? on : 0.0;       // point_filter, SVGDICP.cpp:331-333
+    const double nn = sqrt(mf * best);                    // SVNICP.cpp:120 on the masked rows
+    const double wq = a.max_dist / (a.max_dist + 3 * nn);
+    const double w = on * (wq * wq);                      // SVNICP.cpp:122 (exactly 1 for a rejected row)
+    const double we = mf * w;
+    const double e0 = we * dx, e1 = we * dy, e2 = we * dz;  // SVNICP.cpp:119,123
+    const double n0 = mf * s0, n1 = mf * s1, n2 = mf * s2;
     const double w0 = w * n0, w1 = w * n1, w2 = w * n2;
     acc[0] += w;
     acc[1] += w0; acc[2] += w1; acc[3] += w2;
     // SVGD mode needs count_nonzero(mask·Ts summed over xyz) (SVGDICP.cpp:404) instead of Σw·s_x²
-    acc[4] = a.svgd ? acc[4] + ((best < a.max_dist && ((T0 + T1) + T2) != 0.0) ? 1.0 : 0.0) : fma(w0, n0, acc[4]);
+    if (!PLAIN && a.svgd) acc[4] += (((T0 + T1) + T2) != 0.0) ? mf : 0.0;
+    else acc[4] = fma(w0, n0, acc[4]);
     acc[5] = fma(w0, n1, acc[5]); acc[6] = fma(w0, n2, acc[6]);
     acc[7] = fma(w1, n1, acc[7]); acc[8] = fma(w1, n2, acc[8]); acc[9] = fma(w2, n2, acc[9]);
     acc[10] += e0; acc[11] += e1; acc[12] += e2;
@@ -643,24 +636,37 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
   };
 
   const int64_t n0 = blk_lo + wb * BW;
-  if (n0 < blk_hi) {
-    // prologue: fill the pipeline (points past the range load harmless clamped addresses)
-    int kb1 = load_kb(n0);
-    int64_t ti1 = load_ti(n0, kb1);
-    Stage cur;
-    fetch(n0, ti1, kb1, cur);
-    kb1 = load_kb(n0 + STEP);                 // point n+STEP: byte, then index
-    ti1 = load_ti(n0 + STEP, kb1);
-    int kb2 = load_kb(n0 + 2 * STEP);         // point n+2·STEP: byte
-    for (int64_t n = n0; n < blk_hi; n += STEP) {  // wave-uniform
-      Stage nxt;
-      nxt.valid = false;
-      if (n + STEP < blk_hi) fetch(n + STEP, ti1, kb1, nxt);
-      kb1 = kb2;
-      ti1 = load_ti(n + 2 * STEP, kb1);
-      kb2 = load_kb(n + 3 * STEP);
-      finish(cur);
-      cur = nxt;
+  int kbn[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) kbn[u] = load_kb(n0 + u * STEP);
+  for (int64_t n = n0; n < blk_hi; n += U * STEP) {  // wave-uniform
+    int kb[U];
+    int64_t ti[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {   // target index of the winner; clamped like k_build_table3
+      kb[u] = kbn[u];
+      const int64_t b = n + u * STEP + bs;
+      const int64_t bl = b < blk_hi ? b : blk_lo;
+      const int64_t t = ccand[(size_t)bl * K + kb[u]];
+      ti[u] = t < 0 ? 0 : (t >= a.M ? a.M - 1 : t);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) kbn[u] = load_kb(n + (U + u) * STEP);
+    double q[U][3];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const SVNICP_CONST_AS double* r = ctgt + 3 * ti[u];
+      q[u][0] = r[0]; q[u][1] = r[1]; q[u][2] = r[2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t b = n + u * STEP + bs;
+      const bool valid = pvalid && b < blk_hi;
+      const int64_t bl = b < blk_hi ? b : blk_lo;
+      const SVNICP_CONST_AS double* sp = csrc + 3 * bl;
+      const double s0 = sp[0], s1 = sp[1], s2 = sp[2];
+      if (!PLAIN && a.corr && valid) a.corr[(size_t)p * a.B + b] = kb[u];
+      accumulate(b < blk_hi ? 1.0 : 0.0, s0, s1, s2, q[u][0], q[u][1], q[u][2]);
     }
   }
 
@@ -735,7 +741,8 @@ hipError_t launch_srb(const AccumPlan& plan, const AccumArgs& a, hipStream_t st)
 }
 template <int PW, int WP>
 hipError_t launch_w(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((k_stein_accumulate_w<PW, WP>), dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
+  if (!a.svgd && !a.corr) hipLaunchKernelGGL((k_stein_accumulate_w<PW, WP, true>), dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
+  else hipLaunchKernelGGL((k_stein_accumulate_w<PW, WP, false>), dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
   return hipGetLastError();
 }
 
@@ -759,7 +766,7 @@ void occ_split(int K, size_t smem, bool f32, int* search, int* accum) {
   }
   *search = (e != hipSuccess || n < 1) ? 4 : (n > 8 ? 8 : n);
   n = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_accumulate_w<PW, WP>, NT, smem);
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stein_accumulate_w<PW, WP, true>, NT, smem);
   *accum = (e != hipSuccess || n < 1) ? 3 : (n > 8 ? 8 : n);
 }
 

@@ -5,19 +5,26 @@
 
 A *step* is one full registration of one synthetic 64-beam scan pair through the C ABI:
 add_cloud (device→device copy of the resident clouds + particle reset) → set_initial_mean →
-stein_align (stage A exact top-K + I fused Stein iterations) → result getters.  The clouds are
-resident in HBM before the timed region starts.  N = 1 runs the headline configuration C3
-(128 particles × 131 072 source / 262 144 target points, K = 100, I = 20, float64).  N > 1
-keeps the clouds and shards 128·N particles 128 per GPU (weak scaling in the particle axis) with
-one all-gather of 176 B per particle per iteration over RCCL.
+stein_align (stage A exact top-K + I Stein iterations) → result getters.  The clouds are
+resident in HBM before the timed region starts.
+
+N = 1 runs the headline configuration C3 (128 particles × 131 072 source / 262 144 target points,
+K = 100, I = 20, float64); `value` = registrations/s.
+N > 1 runs BASELINE configuration C4 — 512 particles FIXED, sharded 512/N per GPU, one all-gather of
+176 B per particle per iteration over RCCL — so `value` is the raw registrations/s of the same
+512-particle registration at every N (`"scaling": "strong"`).  Next to it the line carries
+`speedup_vs_1gpu` (rank 0 times the unsharded 512-particle registration on its own GPU in the same
+invocation, outside the timed region) and a `weak_scaling` record (C3 clouds, 128 particles per GPU,
+raw registrations/s).  The N = 1 line carries the one-GPU C4 rate as `c4_one_gpu` so that the
+strong-scaling curve has its first point.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      — the dominant kernel (k_stein_search_mfma at C3) against the dense f32 MFMA peak, from
-                  live hipEvent timings on the library's stream,
-  roofline_hbm / roofline_valu — the same kernel against the other roofs (the nearest-candidate search is
-                  bound by vector/matrix issue, not by HBM: SURVEY.md §8d), and per-kernel details,
+  roofline      — the dominant kernel (k_stein_search_bf16 at C3): algorithmic flops of the reference's brute
+                  force per launch time against the f32 matrix/vector peak, from live hipEvent timings on the
+                  library's stream; roofline_hbm is the HBM view of the same kernel,
   cpu_baseline  — the CPU oracle ("port": oracle/svnicp_oracle.c, OpenMP) timed on this box's host
-                  cores on a bounded sample of the same workload (rank 0, N = 1 only).
+                  cores on the same workload (rank 0, N = 1 only),
+  svn_full_grad — the same registration with SVNFullGrad = true (BASELINE.md §2 reports both branches).
 """
 from __future__ import annotations
 
@@ -35,7 +42,8 @@ import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_VALU_PEAK_TF = 78.6    # MI355X f64 vector peak (FMA counted as 2 flop); 39.3 T non-fused op/s
-F32_MFMA_PEAK_TF = 157.3   # MI355X dense f32-input MFMA peak (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
+F32_MFMA_PEAK_TF = 157.3   # MI355X dense f32-input MFMA peak = f32 vector peak, MI355X_MICROARCH.md
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -43,11 +51,32 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, help="C1|C2|C3|C4|C5 (default: C3; N>1: C3 clouds, 128 particles per GPU)")
+    ap.add_argument("--workload", default=None, help="C1|C2|C3|C4|C5 (default: C3 at N = 1, C4 = 512 particles fixed at N > 1)")
     ap.add_argument("--full-grad", type=int, default=0, help="SVNFullGrad (shipped default false)")
-    ap.add_argument("--cpu-sample", type=int, default=16384, help="source points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="source points of the CPU-baseline sample, evenly spaced over the scan (-1 = the whole source, 0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent brackets")
+    ap.add_argument("--mode", default="svn", choices=("svn", "svgd"), help="svn (headline) | svgd (first-order sibling, N = 1)")
     return ap.parse_args()
+
+
+def time_steps(step, n, world, dist, torch, dev):
+    """Barrier + synchronize on both sides, max over ranks; returns seconds for n steps."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return el
 
 
 def main():
@@ -62,42 +91,54 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # rehearsal switch (one-GPU box): SVNICP_BENCH_REHEARSAL=1 puts every rank on cuda:0 and runs the collectives over gloo
+    # (host-staged) — it exercises the N > 1 control flow, its numbers mean nothing
+    rehearsal = os.environ.get("SVNICP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pkg = graft.load_package()
     scans = pkg.scans
-    wl = a.workload or "C3"
+    wl = a.workload or ("C3" if world == 1 else "C4")
     cfg = dict(scans.CONFIGS[wl])
-    if world > 1 and a.workload is None:
-        cfg["P"] = 128 * world
     P, B, M, I = cfg["P"], cfg["B"], cfg["M"], cfg["I"]
     K = 100
     pair = scans.make_pair(B, M)
     init = scans.make_particles(P)
-    prm = pkg.SteinICPParam(iterations=I, lr=1.0, max_dist=1.0, KNN_count=K, SVN_full_grad=bool(a.full_grad),
-                            check_early_stop=False)
+    svgd = a.mode == "svgd"
+
+    def make_param(full_grad):
+        return pkg.SteinICPParam(iterations=I, lr=(0.01 if svgd else 1.0), max_dist=1.0, KNN_count=K,
+                                 SVN_full_grad=bool(full_grad), check_early_stop=False, optimizer="Adam")
+    prm = make_param(a.full_grad)
     src_d = torch.from_numpy(pair.source).to(dev)
     tgt_d = torch.from_numpy(pair.target).to(dev)
     T0 = np.eye(4)
 
+    def make_step(solver, particles):
+        def step():
+            solver.add_cloud(src_d, tgt_d, particles)
+            solver.set_initial_mean(T0)
+            st = solver.stein_align()
+            return st, solver.get_transformation(), solver.get_cov_matrix()
+        return step
+
     if world == 1:
-        solver = pkg.SVNICP(prm, init, pkg.ParticleWeightOpt(), device=local_rank)
+        solver = (pkg.SVGDICP(prm, init, device=local_rank) if svgd else
+                  pkg.SVNICP(prm, init, pkg.ParticleWeightOpt(), device=local_rank))
         if not a.no_profile:
             solver.set_profile(True)
     else:
         from svnicp_amd.sharded import ShardedSVNICP
         solver = ShardedSVNICP(prm, init, device_index=local_rank)
-
-    def step():
-        solver.add_cloud(src_d, tgt_d, init)
-        solver.set_initial_mean(T0)
-        st = solver.stein_align()
-        mean = solver.get_transformation()
-        cov = solver.get_cov_matrix()
-        return st, mean, cov
+    step = make_step(solver, init)
 
     kernel_ms = {}
     for i in range(a.warmup):
@@ -112,12 +153,11 @@ def main():
         solver.set_profile(True, timed_classes)
         for k in timed_classes:
             kernel_ms[k] = [0.0, 0]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
+    last = {}
+
+    def timed_step():
         st, mean, cov = step()
+        last["mean"] = mean
         if world == 1 and not a.no_profile:
             for k, (ms, n) in solver.get_kernel_ms().items():
                 if a.warmup > 0 and k not in timed_classes:
@@ -125,54 +165,77 @@ def main():
                 acc = kernel_ms.setdefault(k, [0.0, 0])
                 acc[0] += ms
                 acc[1] += n
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    el = time_steps(timed_step, a.steps, world, dist, torch, dev)
+    mean = last["mean"]
 
     pose_err = np.abs(mean - pair.true_pose)
+    mode_name = "SVGD-ICP (Adam, lr 0.01)" if svgd else "SVN-ICP"
     out = {
         "metric": "scan-pair registrations/sec at N particles x M source pts, 1/2/4/8 GPU",
-        # whole-job aggregate: a registration of 128·N particles sharded over N GPUs counts as N of the
-        # 128-particle registrations the metric is quoted on (weak scaling: per-GPU work fixed)
-        "value": (P / 128.0 if world > 1 else 1.0) * a.steps / el,
-        "unit": "registrations/s" if world == 1 else "registrations/s (128-particle equivalents: one 128*N-particle registration = N)",
+        "value": a.steps / el,                      # raw registrations per second of the named workload, whole job
+        "unit": "registrations/s",
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": 1e3 * el / a.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": f"{wl}: {P} particles SVN-ICP, {B}-pt source vs {M}-pt target, K={K}, I={I}, "
-                               f"max_dist=1.0, lr=1.0, SVNFullGrad={bool(a.full_grad)}, early stop off; synthetic 64-beam "
+        "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo — not a measurement)",
+        "config": {"workload": f"{wl}: {P} particles {mode_name}, {B}-pt source vs {M}-pt target, K={K}, I={I}, "
+                               f"max_dist=1.0, lr={prm.lr}, SVNFullGrad={bool(a.full_grad)}, early stop off; synthetic 64-beam "
                                f"scans (seed {scans.SEED})",
                    "particles": P, "source_points": B, "target_points": M, "knn_count": K, "iterations": I,
-                   "parallelism": "single GPU" if world == 1 else f"particles sharded {P // world}/GPU, all-gather of "
-                                                                     "176 B/particle/iteration (RCCL)"},
-        "registrations_per_s_raw": a.steps / el,
+                   "parallelism": "single GPU" if world == 1 else f"{P} particles fixed, sharded {P // world}/GPU; stage A "
+                                  f"sharded by source rows; one all-gather of 176 B/particle/iteration (RCCL, world size "
+                                  f"{dist.get_world_size()} as reported by the process group)"},
         "particle_registrations_per_s": P * a.steps / el,
         "pose_error_vs_planted": {"trans_m": float(pose_err[:3].max()), "rot_rad": float(pose_err[3:].max())},
     }
 
+    nside = max(2, min(5, a.steps))
+    if world > 1:
+        # strong-scaling reference: the same 512-particle registration, unsharded, on rank 0's GPU (others wait)
+        one = None
+        if rank == 0:
+            ref = pkg.SVNICP(prm, init, pkg.ParticleWeightOpt(), device=local_rank)
+            rstep = make_step(ref, init)
+            rstep()
+            one = time_steps(rstep, nside, 1, dist, torch, dev) / nside
+            ref.close()
+        dist.barrier()
+        # weak-scaling record: C3 clouds, 128 particles per GPU (per-GPU work fixed)
+        cfgw = scans.CONFIGS["C3"]
+        Pw = 128 * world
+        if (cfgw["B"], cfgw["M"]) != (B, M):
+            pw = scans.make_pair(cfgw["B"], cfgw["M"])
+            src_d = torch.from_numpy(pw.source).to(dev); tgt_d = torch.from_numpy(pw.target).to(dev)
+        initw = scans.make_particles(Pw)
+        sw = ShardedSVNICP(prm, initw, device_index=local_rank)
+        wstep = make_step(sw, initw)
+        wstep()
+        elw = time_steps(wstep, nside, world, dist, torch, dev)
+        if rank == 0:
+            out["one_gpu_ms_per_step"] = 1e3 * one
+            out["speedup_vs_1gpu"] = one / (el / a.steps)
+            out["weak_scaling"] = {"workload": f"C3 clouds, {Pw} particles = 128 per GPU", "registrations_per_s": nside / elw,
+                                   "ms_per_step": 1e3 * elw / nside, "particle_registrations_per_s": Pw * nside / elw}
+
     if world == 1 and kernel_ms:
         # Algorithmic work per launch (SURVEY.md §8d per-unit figures): 8 unfused f64 flop
         # per point-pair distance of the reference's brute force; bytes = clouds/candidates in + results out.
+        split = bool(kernel_ms.get("k_stein_search", (0, 0))[1])
         work = {
-            "stage_a_knn": dict(bytes=24.0 * (B + M) + 12.0 * B * K, flops=8.0 * B * M),
+            # stage A prunes exactly (Morton tiles + f32 pre-filter): its brute-force flop count is not work it does, so
+            # only the algorithmic bytes and the brute-force pair count are reported for it
+            "stage_a_knn": dict(bytes=24.0 * (B + M) + 12.0 * B * K, pairs_bruteforce=float(B) * M),
             # split stage B: the search kernel reads the float32 candidate rows (16 B each) and the source points and
             # writes one winner byte per (point, particle); the accumulate kernel reads the bytes, the source points
             # and one winner (24 B) per pair.  Fused variants: everything is in the k_stein_accumulate class.
             "k_stein_search": dict(bytes=16.0 * B * K + 24.0 * B + 1.0 * P * B, flops=8.0 * P * B * K),
-            "k_stein_accumulate": dict(bytes=(24.0 * B + 25.0 * P * B) if kernel_ms.get("k_stein_search", (0, 0))[1]
-                                       else (24.0 * B + 24.0 * B * K),
-                                       flops=(60.0 * P * B) if kernel_ms.get("k_stein_search", (0, 0))[1] else 8.0 * P * B * K),
+            "k_stein_accumulate": dict(bytes=(24.0 * B + 25.0 * P * B) if split else (24.0 * B + 24.0 * B * K),
+                                       flops=(60.0 * P * B) if split else 8.0 * P * B * K),
         }
         traffic = {}
         try:
@@ -189,9 +252,13 @@ def main():
             if k in work:
                 avg_s = ms / max(n, 1) * 1e-3
                 d["alg_GBps"] = work[k]["bytes"] / avg_s / 1e9
-                d["alg_TFLOPs"] = work[k]["flops"] / avg_s / 1e12
+                if "flops" in work[k]:
+                    d["alg_TFLOPs"] = work[k]["flops"] / avg_s / 1e12
+                else:
+                    d["pairs_bruteforce"] = work[k]["pairs_bruteforce"]
+                    d["note"] = "exact pruned search: the brute-force pair count is the reference's work, not this kernel's"
             details[k] = d
-        dom = max(work, key=lambda k: kernel_ms.get(k, (0, 0))[0])
+        dom = max((k for k in work if "flops" in work[k]), key=lambda k: kernel_ms.get(k, (0, 0))[0])
         avg_s = kernel_ms[dom][0] / max(kernel_ms[dom][1], 1) * 1e-3
         gbs = work[dom]["bytes"] / avg_s / 1e9
         tf = work[dom]["flops"] / avg_s / 1e12
@@ -199,13 +266,19 @@ def main():
         hbm = {"kernel": dom, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                "traffic": tr}
         if dom == "k_stein_search":
-            # the dominant kernel's scores come off the f32 matrix cores: price it against the dense f32 MFMA peak with
-            # the ALGORITHMIC flops of the reference's brute force (8 per candidate-particle pair)
-            out["roofline"] = {"kernel": "k_stein_search_mfma", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF,
+            # The scores are float32-accurate quantities: 8 algorithmic flop per (candidate, particle) pair of the
+            # reference's brute force, priced against the f32 matrix/vector peak (157.3 TF).  They are
+            # produced on the bf16 matrix pipe as exact three-way operand splits (K = 32 per tile instead of 4), so the
+            # flops the matrix pipe EXECUTES are 8x the algorithmic ones (reported below against the bf16 peak).
+            mfma_exec_tf = 2.0 * 16 * 16 * 32 * (B * ((P + 15) // 16) * ((K // 16) if K % 16 < 5 else (K + 15) // 16)) / avg_s / 1e12
+            out["roofline"] = {"kernel": "k_stein_search_bf16", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF,
                                "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF, "traffic": tr,
-                               "note": "f32 MFMA tiles + 3 VALU tracking ops per score share the SIMD issue (PMC in "
-                                       "profiles/): VALU 60 % + MFMA 25 % busy, never co-executing; the HBM view of the same kernel is roofline_hbm; "
-                                       "traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/traffic.json)"}
+                               "executed_bf16_TFLOPs": mfma_exec_tf, "executed_frac_of_bf16_peak": mfma_exec_tf / BF16_MFMA_PEAK_TF,
+                               "note": "nearest-of-K scores on v_mfma_f32_16x16x32_bf16 (exact bf16x3 splits) + 3 VALU "
+                                       "tracking ops per score; the kernel is bound by vector-instruction issue (one "
+                                       "instruction per ~4 cycles per SIMD, PMC in profiles/), not by the matrix pipe or "
+                                       "HBM; roofline_hbm is the HBM view; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE "
+                                       "per launch (profiles/traffic.json)"}
             out["roofline_hbm"] = hbm
         else:
             hbm["note"] = ("nearest-neighbour search is VALU-bound, not HBM-bound (SURVEY.md §8d): see roofline_valu; traffic = "
@@ -218,22 +291,53 @@ def main():
                                             "this is an effective rate, not an instruction count"}
         out["kernels"] = details
 
-    if rank == 0 and world == 1 and a.cpu_sample > 0:
+    if world == 1 and not svgd and wl == "C3":
+        # side records (few untimed-region steps each): SVNFullGrad = true, the one-GPU point of the C4 strong-scaling curve,
+        # and the host cost of the multi-GPU driver (ShardedSVNICP at world size 1 against svnicp_align)
+        solver.set_profile(False)
+        s2 = pkg.SVNICP(make_param(not a.full_grad), init, pkg.ParticleWeightOpt(), device=local_rank)
+        st2 = make_step(s2, init); st2()
+        e2 = time_steps(st2, nside, 1, dist, torch, dev)
+        out["svn_full_grad" if not a.full_grad else "svn_default_grad"] = {"registrations_per_s": nside / e2, "ms_per_step": 1e3 * e2 / nside}
+        s2.close()
+        c4 = scans.CONFIGS["C4"]
+        init4 = scans.make_particles(c4["P"])
+        s4 = pkg.SVNICP(prm, init4, pkg.ParticleWeightOpt(), device=local_rank)
+        st4 = make_step(s4, init4); st4()
+        e4 = time_steps(st4, nside, 1, dist, torch, dev)
+        out["c4_one_gpu"] = {"workload": f"C4 on one GPU: {c4['P']} particles, C3 clouds", "registrations_per_s": nside / e4,
+                             "ms_per_step": 1e3 * e4 / nside}
+        s4.close()
+        from svnicp_amd.sharded import ShardedSVNICP
+        ss = ShardedSVNICP(prm, init, device_index=local_rank)
+        sst = make_step(ss, init); sst()
+        es_ = time_steps(sst, nside, 1, dist, torch, dev)
+        plain = make_step(solver, init); plain()
+        ep = time_steps(plain, nside, 1, dist, torch, dev)
+        out["sharded_driver_world1"] = {"ms_per_step": 1e3 * es_ / nside, "svnicp_align_ms_per_step": 1e3 * ep / nside,
+                                        "host_overhead_ms": 1e3 * (es_ - ep) / nside}
+
+    if rank == 0 and world == 1 and a.cpu_sample != 0:
         orc = graft.load_oracle()
-        Bs = min(a.cpu_sample, B)
-        o = orc.Solver(init, iterations=I, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=bool(a.full_grad))
-        o.add_cloud(pair.source[:Bs], pair.target, init)
+        Bs = B if a.cpu_sample < 0 else min(a.cpu_sample, B)
+        rows = np.linspace(0, B - 1, Bs).astype(np.int64)      # evenly spaced over the scan, not its first beams
+        o = orc.Solver(init, mode=(orc.MODE_SVGD if svgd else orc.MODE_SVN), iterations=I, lr=prm.lr, max_dist=1.0,
+                       knn_count=K, svn_full_grad=bool(a.full_grad), optimizer="Adam")
+        o.add_cloud(np.ascontiguousarray(pair.source[rows]), pair.target, init)
         t1 = time.perf_counter()
         o.stein_align()
         tc = time.perf_counter() - t1
         full = tc * (B / Bs)  # stage A and stage B are both linear in the source size
+        sample = (f"the whole {B}-pt source" if Bs == B else f"{Bs} of {B} source points, evenly spaced, scaled x{B / Bs:.1f} "
+                  "(cost is linear in the source size)")
         out["cpu_baseline"] = {"value": 1.0 / full, "unit": "registrations/s", "cores": orc.get_threads(), "kind": "port",
-                               "sample": f"oracle/svnicp_oracle.c (OpenMP, f64) on the first {Bs} of {B} source points "
-                                         f"against the full {M}-pt target, P={P}, K={K}, I={I}: {tc:.2f} s, scaled x{B / Bs:.0f} "
-                                         "(cost is linear in the source size)",
+                               "sample": f"oracle/svnicp_oracle.c (OpenMP, f64) on {sample} against the full {M}-pt target, "
+                                         f"P={P}, K={K}, I={I}: {tc:.2f} s",
                                "host_cpus": os.cpu_count()}
-        # sanity: the sample's pose must agree with the GPU's full-cloud pose to ~cm (different point sets)
-        out["cpu_baseline"]["pose_sample"] = [float(v) for v in o.get_transformation()]
+        op = o.get_transformation()
+        out["cpu_baseline"]["pose"] = [float(v) for v in op]
+        if Bs == B:
+            out["cpu_baseline"]["max_abs_pose_diff_vs_gpu"] = float(np.abs(op - mean).max())
 
     if rank == 0:
         print(json.dumps(out))

@@ -97,7 +97,9 @@ class HipBackend:
         self._chk(self._L.svnicp_finish(self._h), "svnicp_finish")
 
     def stopped(self) -> bool:
-        return bool(self._L.svnicp_stopped(self._h))
+        rc = self._L.svnicp_stopped(self._h)   # 1 / 0, or a negative svnicp_status
+        self._chk(rc, "svnicp_stopped")
+        return rc > 0
 
     def synchronize(self):
         self.torch.cuda.current_stream(self.device).synchronize()
@@ -137,6 +139,7 @@ class ShardedSVNICP:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.param = param
+        self.stop_poll = 4
         if backend is None:
             import torch
             if device_index is None:
@@ -165,7 +168,10 @@ class ShardedSVNICP:
             if W > 1:
                 _all_gather_rows(self.dist, self.group, be.records_tensor(), p_lo, p_hi, W, r)
             be.iter_update(it)
-            if self.param.check_early_stop and be.stopped():
+            # the early-stop flag lives on the device and later launches return at once when it is set, so the host only
+            # looks (a device-to-host copy + stream sync) every few iterations; all ranks see the same flag value because
+            # the update runs on identical inputs
+            if self.param.check_early_stop and (it % self.stop_poll == self.stop_poll - 1) and be.stopped():
                 break
         be.finish()
         be.synchronize()

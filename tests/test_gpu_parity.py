@@ -417,6 +417,51 @@ def test_two_processes_one_gpu_sharded_driver(hip, tmp_path):
     assert np.allclose(r0["particles"], ref.get_particles(), rtol=0, atol=1e-12)
 
 
+def _two_rank_nccl_worker(rank, world, port, out_dir):
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as graft
+    import torch
+    import torch.distributed as dist
+    pkg = graft.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from svnicp_amd.sharded import ShardedSVNICP
+    P, B, M = 37, 3001, 20000          # ragged particle shards and ragged source rows: padded all-gathers
+    src, tgt = pkg.scans.random_clouds(B, M, seed=23, extent=25.0)
+    init = pkg.scans.make_particles(P, seed=23) * 0.3
+    prm = pkg.SteinICPParam(iterations=5, lr=1.0, max_dist=1.0, KNN_count=40, SVN_full_grad=True)
+    s = ShardedSVNICP(prm, init, device_index=rank)
+    s.add_cloud(src, tgt, init); s.set_initial_mean(np.eye(4)); s.stein_align()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), particles=s.get_particles(), cov=s.get_cov_matrix(),
+             cand=s.get_candidates())
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_gpus_rccl_sharded_driver(hip, tmp_path):
+    """The RCCL branch of the sharded driver (in-place all-gathers into library-owned device memory through
+    __cuda_array_interface__) on two real GPUs: replicas bit-identical, equal to the single-process run.
+    Skipped on a one-GPU box — the driver's multi-GPU node runs it."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_two_rank_nccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = (np.load(str(tmp_path / f"r{r}.npz")) for r in range(2))
+    assert np.array_equal(r0["particles"], r1["particles"]) and np.array_equal(r0["cov"], r1["cov"])
+    P, B, M = 37, 3001, 20000
+    src, tgt = hip.scans.random_clouds(B, M, seed=23, extent=25.0)
+    init = hip.scans.make_particles(P, seed=23) * 0.3
+    ref = hip.SVNICP(hip.SteinICPParam(iterations=5, lr=1.0, max_dist=1.0, KNN_count=40, SVN_full_grad=True), init)
+    ref.add_cloud(src, tgt, init); ref.stein_align()
+    assert np.array_equal(r0["cand"], ref.get_candidates())
+    assert np.allclose(r0["particles"], ref.get_particles(), rtol=0, atol=1e-12)
+
+
 # ------------------------------------------------------------------ BASELINE sizes
 def test_c1_full_parity(hip, orc):
     """BASELINE config C1 (the reference-CPU-path config): 1 particle, 4096 x 8192, 20 iterations."""

@@ -126,3 +126,19 @@ def test_parameters_and_variance_layouts(sm):
     v = sm.fill_variance(np.arange(6.0), stamp=1.0)
     assert len(sm.encode(v)) == 4 + (8 + 4 + 1 + 3) + 4 * 6 * 8  # body: header (13 bytes) padded to 16, then four float64[6]
     assert "float64[] x" in sm.msg_definition("stein_msgs/SteinParticle") and "SteinParticle[] stein_particle_array" in sm.msg_definition("stein_msgs/SteinParticleArray")
+
+
+def test_committed_msg_files_match_the_schemas(pkg):
+    """stein_msgs/msg/*.msg (the interface package a colcon workspace builds) are the generator's output and parse back
+    into the schemas the CDR codec uses: the five message types, field order and types as upstream's stein_msgs."""
+    import glob, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sm = pkg.stein_msgs
+    files = sorted(glob.glob(os.path.join(root, "stein_msgs", "msg", "*.msg")))
+    assert [os.path.basename(f)[:-4] for f in files] == ["Runtime", "SteinParameters", "SteinParticle", "SteinParticleArray", "Variance"]
+    for f in files:
+        tn = "stein_msgs/" + os.path.basename(f)[:-4]
+        text = open(f).read()
+        assert text == sm.msg_definition(tn)
+        parsed = [tuple(line.split()) for line in text.splitlines() if line.strip()]
+        assert [name for _, name in parsed] == [name for name, _ in sm.SCHEMAS[tn]]

@@ -1,0 +1,68 @@
+// pipeline_drive.cpp — runs svnicp::RegistrationPipeline (registration_pipeline.hpp) over a recorded sequence of scans and
+// dumps, per scan, what the pipeline handed to the solver and what it got back.  Used by tests/test_pipeline_gpu.py, which
+// replays the dumped solver inputs through the CPU oracle and through svn-icp_amd/pipeline.py.
+//   g++ -std=c++17 -I include -I svn-icp_amd/host pipeline_drive.cpp -L svn-icp_amd -lsvnicp_hip -o pipeline_drive
+//   pipeline_drive scans.bin out.bin P iterations knn voxel [particles.bin]
+// scans.bin : int32 n_scans, then per scan { f64 stamp, int32 n, n x 3 float32 }
+// particles : optional f64 [n_scans][6][P] (otherwise the built-in uniform prior sampler)
+// out.bin   : per scan { int32 aligned, f64 pose[12], guess[12], corr[6], var[6], cov[36], int64 B, M, f64 src[3B], tgt[3M], init[6P] }
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "registration_pipeline.hpp"
+
+template <typename T> static bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
+template <typename T> static void wr(FILE* f, const T* p, size_t n) { fwrite(p, sizeof(T), n, f); }
+
+int main(int argc, char** argv) {
+  if (argc < 7) { fprintf(stderr, "usage: %s scans.bin out.bin P iterations knn voxel [particles.bin]\n", argv[0]); return 64; }
+  FILE* fi = fopen(argv[1], "rb");
+  FILE* fo = fopen(argv[2], "wb");
+  if (!fi || !fo) { perror("open"); return 65; }
+  svnicp::PipelineConfig cfg;
+  cfg.particle_count = atoi(argv[3]);
+  cfg.solver.iterations = atoi(argv[4]); cfg.solver.KNN_count = atoi(argv[5]);
+  cfg.solver.lr = 1.0; cfg.solver.max_dist = 1.0; cfg.solver.SVN_full_grad = false;
+  cfg.voxel_size = cfg.map_voxel_size = atof(argv[6]);
+  cfg.min_range = 1.0; cfg.max_range = 80.0; cfg.map_range = 100.0; cfg.map_voxel_max_points = 20;
+  FILE* fp = argc > 7 ? fopen(argv[7], "rb") : nullptr;
+  try {
+    svnicp::RegistrationPipeline pipe(cfg);
+    svnicp::Tap tap;
+    pipe.set_tap(&tap);
+    std::vector<double> injected((size_t)6 * cfg.particle_count);
+    if (fp) pipe.set_particle_source([&](int P, double* out) { for (int i = 0; i < 6 * P; ++i) out[i] = injected[i]; });
+    int32_t n_scans = 0;
+    if (!rd(fi, &n_scans, 1)) return 66;
+    for (int s = 0; s < n_scans; ++s) {
+      double stamp; int32_t n;
+      if (!rd(fi, &stamp, 1) || !rd(fi, &n, 1)) return 66;
+      svnicp::Cloud pts((size_t)n);
+      if (!rd(fi, &pts[0][0], (size_t)3 * n)) return 66;
+      if (fp && !rd(fp, injected.data(), injected.size())) return 66;
+      tap = svnicp::Tap{};
+      const svnicp::ScanResult r = pipe.process_scan(pts, stamp);
+      const int32_t aligned = r.aligned ? 1 : 0;
+      wr(fo, &aligned, 1);
+      double pose[12], guess[12];
+      for (int i = 0; i < 9; ++i) { pose[i] = r.pose.R[i]; guess[i] = r.initial_guess.R[i]; }
+      for (int i = 0; i < 3; ++i) { pose[9 + i] = r.pose.t[i]; guess[9 + i] = r.initial_guess.t[i]; }
+      wr(fo, pose, 12); wr(fo, guess, 12);
+      std::vector<double> cov = r.cov; cov.resize(36, 0.0);
+      wr(fo, r.correction.data(), 6); wr(fo, r.variance.data(), 6); wr(fo, cov.data(), 36);
+      const int64_t B = (int64_t)tap.source.size() / 3, M = (int64_t)tap.target.size() / 3;
+      wr(fo, &B, 1); wr(fo, &M, 1);
+      wr(fo, tap.source.data(), tap.source.size()); wr(fo, tap.target.data(), tap.target.size());
+      tap.particles.resize((size_t)6 * cfg.particle_count, 0.0);
+      wr(fo, tap.particles.data(), tap.particles.size());
+      printf("scan %d: aligned %d  B %lld  M %lld  voxels %zu  pose t = %.4f %.4f %.4f\n", s, aligned, (long long)B, (long long)M,
+             pipe.map().Size(), r.pose.t[0], r.pose.t[1], r.pose.t[2]);
+    }
+  } catch (const std::exception& e) {
+    fprintf(stderr, "svnicp: %s\n", e.what());
+    return 3;  // e.g. no gfx950 device: the library has no CPU path
+  }
+  fclose(fo); fclose(fi);
+  return 0;
+}

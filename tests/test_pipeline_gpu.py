@@ -41,3 +41,92 @@ def test_registration_pipeline_tracks_a_synthetic_drive(hip):
     assert ez.max() < 0.03 and est[-1][2, 3] > 0.9 * truth[-1][2, 3]
     assert eyaw[-1] < 0.01
     assert len(pipe.map) > 1000
+
+
+def _build_pipeline_drive(root):
+    import os, subprocess
+    exe = os.path.join(root, "svn-icp_amd", "host", "pipeline_drive")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-I",
+                           os.path.join(root, "svn-icp_amd", "host"), os.path.join(root, "svn-icp_amd", "host", "pipeline_drive.cpp"),
+                           "-L", os.path.join(root, "svn-icp_amd"), "-lsvnicp_hip", "-Wl,-rpath," + os.path.join(root, "svn-icp_amd"),
+                           "-o", exe])
+    return exe
+
+
+def test_cpp_registration_pipeline_against_oracle_and_python(hip, orc, tmp_path):
+    """The header-only C++ registration_pipeline (svn-icp_amd/host/registration_pipeline.hpp: crop, uniform down-sample,
+    constant-twist prediction, voxel-hash local map, solver, pose = prediction · correction, map insert —
+    OdometryPipeline.cpp:556-647) over a synthetic drive.  For every registered scan the solver inputs the pipeline
+    captured (source, target, initial guess, particles) are replayed through the CPU oracle: mean, variance, covariance
+    and the composed pose must agree to 1e-9.  The Python pipeline (pipeline.py) run on the same scans and particles is
+    the cross-check of the host-side stages: same source clouds, same poses."""
+    import importlib, os, struct, subprocess
+    pl = importlib.import_module(hip.__name__ + ".pipeline")
+    sc = hip.scans
+    root = os.path.dirname(os.path.dirname(hip.library_path()))
+    exe = _build_pipeline_drive(root)
+    P, I, K, voxel, n_scans = 24, 12, 40, 0.5, 6
+    scene = sc.make_scene()
+    rng = np.random.default_rng(11)
+    scans, parts = [], []
+    for k in range(n_scans):
+        t = np.array([0.0, 0.0, 0.05 * k]); R = sc.rot_zyx(0.0, 0.0, np.radians(0.3 * k))
+        scans.append((0.1 * k, sc.lidar_scan(scene, R, t, 16384, stream=700 + k).astype(np.float32)))
+        parts.append(hip.initialize_particles(P, pl.PRIOR_UB, pl.PRIOR_LB, rng))
+    with open(tmp_path / "scans.bin", "wb") as f:
+        f.write(struct.pack("<i", n_scans))
+        for stamp, pts in scans:
+            f.write(struct.pack("<di", stamp, pts.shape[0])); f.write(np.ascontiguousarray(pts[:, :3], np.float32).tobytes())
+    with open(tmp_path / "particles.bin", "wb") as f:
+        for p in parts:
+            f.write(np.ascontiguousarray(p, np.float64).tobytes())
+    r = subprocess.run([exe, str(tmp_path / "scans.bin"), str(tmp_path / "out.bin"), str(P), str(I), str(K), str(voxel),
+                        str(tmp_path / "particles.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(tmp_path / "out.bin", "rb").read()
+    off = 0
+
+    def take(fmt_dtype, n):
+        nonlocal off
+        a = np.frombuffer(raw, fmt_dtype, n, off); off += a.nbytes
+        return a
+    recs = []
+    for k in range(n_scans):
+        aligned = int(take("<i4", 1)[0])
+        pose, guess = take("<f8", 12), take("<f8", 12)
+        corr, var, cov = take("<f8", 6), take("<f8", 6), take("<f8", 36)
+        B, M = (int(v) for v in take("<i8", 2))
+        src, tgt, init = take("<f8", 3 * B).reshape(B, 3), take("<f8", 3 * M).reshape(M, 3), take("<f8", 6 * P).reshape(6, P)
+        recs.append(dict(aligned=aligned, pose=pose, guess=guess, corr=corr, var=var, cov=cov, src=src, tgt=tgt, init=init))
+    assert off == len(raw) and recs[0]["aligned"] == 0 and all(rc["aligned"] == 1 for rc in recs[1:])
+
+    def mat(p12):
+        T = np.eye(4); T[:3, :3] = p12[:9].reshape(3, 3); T[:3, 3] = p12[9:]
+        return T
+    # (1) the solver call of every scan against the oracle on the captured inputs
+    for k, rc in enumerate(recs[1:], 1):
+        assert np.array_equal(rc["init"], parts[k])
+        G = mat(rc["guess"])
+        o = orc.Solver(rc["init"], iterations=I, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
+        o.add_cloud(rc["src"], rc["tgt"], rc["init"]); o.set_initial_mean(G[:3, :3], G[:3, 3]); o.stein_align()
+        assert np.abs(rc["corr"] - o.get_transformation()).max() < 1e-9, k
+        assert np.allclose(rc["var"], o.get_distribution(), rtol=0, atol=1e-9)
+        assert np.allclose(rc["cov"], o.get_cov_matrix(), rtol=0, atol=1e-9)
+        assert np.allclose(mat(rc["pose"]), G @ pl.correction_to_pose(o.get_transformation()), rtol=0, atol=1e-9)   # updater_, :37-46
+    # (2) the host-side stages against pipeline.py (same scans, same particles)
+    cfg = pl.PipelineConfig(min_range=1.0, max_range=80.0, voxel_size=voxel, map_voxel_size=voxel, map_voxel_max_points=20,
+                            map_range=100.0, particle_count=P,
+                            solver=hip.SteinICPParam(iterations=I, lr=1.0, max_dist=1.0, KNN_count=K, SVN_full_grad=False))
+    pipe = pl.RegistrationPipeline(cfg, device=0)
+    it = iter(parts)
+    pipe._particles = lambda: next(it)
+    for k, (stamp, pts) in enumerate(scans):
+        res = pipe.process_scan(pts, stamp)
+        # float32 map transforms are summed in another order in numpy: a few points change voxel, the target sets differ by
+        # a handful of points and the poses at the 1e-5 level
+        assert np.allclose(res.initial_guess, mat(recs[k]["guess"]), rtol=0, atol=2e-4)
+        assert np.allclose(res.pose, mat(recs[k]["pose"]), rtol=0, atol=2e-4), k
+    # same down-sampled source of the last scan, point for point (crop + two uniform samplings, double arithmetic in both)
+    cropped, _ = pl.crop_pointcloud(scans[-1][1], 1.0, 80.0)
+    src_py = pl.downsample_uniform(pl.downsample_uniform(cropped, 0.5 * voxel), 1.5 * voxel)
+    assert np.array_equal(np.asarray(src_py, np.float64), recs[-1]["src"])

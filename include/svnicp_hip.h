@@ -92,6 +92,10 @@ int svnicp_synchronize(svnicp_ctx *ctx);
 int svnicp_set_clouds(svnicp_ctx *ctx, const double *src_xyz, int64_t B, const double *tgt_xyz,
                       int64_t M, int mem_kind);
 int svnicp_set_particles(svnicp_ctx *ctx, const double *init_pose6xP, int P);
+/* the two halves of svnicp_set_clouds, for callers whose clouds live on different sides (host source scan, device
+ * target from svnicp_map_query): each copies its cloud; both must have been given before svnicp_align */
+int svnicp_set_source(svnicp_ctx *ctx, const double *src_xyz, int64_t B, int mem_kind);
+int svnicp_set_target(svnicp_ctx *ctx, const double *tgt_xyz, int64_t M, int mem_kind);
 
 /* SVGDICP::set_initial_mean(gtsam::Pose3) — include/core/SVGDICP.h:102-110.
  * R0 is the rotation matrix row-major (the reference's R0_ after its transpose), t0 the translation. */
@@ -134,6 +138,28 @@ int svnicp_stopped(svnicp_ctx *ctx);     /* 1 once the early-stop flag is set (s
 void *svnicp_candidates_devptr(svnicp_ctx *ctx); /* int32 [B][K] */
 void *svnicp_sums_devptr(svnicp_ctx *ctx);       /* double [P][SVNICP_NSUMS] */
 #define SVNICP_NSUMS 22
+
+/* ---- local map in HBM: svnicp::VoxelHashMap — src/core/VoxelHashMap.cpp:22-101, include/core/VoxelHashMap.h ----------
+ * voxel -> at most max_points points (float32, insertion order); the query result is float64 rows in device memory that
+ * svnicp_set_target(..., SVNICP_MEM_DEVICE) copies device-to-device, so the target never crosses PCIe. */
+typedef struct svnicp_map svnicp_map;
+/* VoxelHashMap(voxel_size, max_range, max_pointscount) — VoxelHashMap.h:39-42; capacity_voxels 0 = default (2^20, grows) */
+int svnicp_map_create(int device, double voxel_size, double max_range, int max_points, int64_t capacity_voxels,
+                      svnicp_map **out);
+void svnicp_map_destroy(svnicp_map *map);
+const char *svnicp_map_last_error(const svnicp_map *map);
+int svnicp_map_clear(svnicp_map *map);                        /* VoxelHashMap::Clear — VoxelHashMap.h:55 */
+int svnicp_map_size(svnicp_map *map, int64_t *voxels);        /* VoxelHashMap::Size / Empty — VoxelHashMap.h:56-57 */
+/* VoxelHashMap::AddPointCloud(cloud, pose) incl. RemoveFarPointCloud — VoxelHashMap.cpp:22-42, 89-97.
+ * xyz: n x 3 float32 (pcl::PointXYZ) in the sensor frame, host or device; pose = rotation (row-major) + translation */
+int svnicp_map_add_cloud(svnicp_map *map, const float *xyz, int64_t n, int mem_kind, const double R_rowmajor[9],
+                         const double t[3]);
+/* VoxelHashMap::GetMap(pose, max_range) — VoxelHashMap.cpp:48-58; center NULL or max_range < 0: GetMap() (:44-46).
+ * The points are written as float64 [count][3] rows into a device buffer owned by the map (valid until the next query),
+ * voxels in ascending (x, y, z) index, points of a voxel in insertion order. */
+int svnicp_map_query(svnicp_map *map, const double center[3], double max_range, int64_t *count_out);
+void *svnicp_map_points_devptr(svnicp_map *map);              /* double [count][3] of the last query */
+int svnicp_map_download(svnicp_map *map, double *out_xyz, int64_t cap_points, int64_t *n_out); /* test tap */
 
 /* ---- test-only taps (parity tests; not part of the reference interface) -------------------- */
 int svnicp_get_candidates(svnicp_ctx *ctx, int32_t *outBK);          /* sourceKNN_idx_  SVGDICP.cpp:214 */

@@ -69,6 +69,20 @@ def load_library():
     L.svnicp_synchronize.argtypes = [vp]
     L.svnicp_set_clouds.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int]
     L.svnicp_set_particles.argtypes = [vp, dp, C.c_int]
+    L.svnicp_set_source.argtypes = [vp, vp, C.c_int64, C.c_int]
+    L.svnicp_set_target.argtypes = [vp, vp, C.c_int64, C.c_int]
+    L.svnicp_map_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_int64, C.POINTER(vp)]
+    L.svnicp_map_destroy.argtypes = [vp]
+    L.svnicp_map_destroy.restype = None
+    L.svnicp_map_last_error.argtypes = [vp]
+    L.svnicp_map_last_error.restype = C.c_char_p
+    L.svnicp_map_clear.argtypes = [vp]
+    L.svnicp_map_size.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.svnicp_map_add_cloud.argtypes = [vp, vp, C.c_int64, C.c_int, dp, dp]
+    L.svnicp_map_query.argtypes = [vp, dp, C.c_double, C.POINTER(C.c_int64)]
+    L.svnicp_map_points_devptr.argtypes = [vp]
+    L.svnicp_map_points_devptr.restype = vp
+    L.svnicp_map_download.argtypes = [vp, dp, C.c_int64, C.POINTER(C.c_int64)]
     L.svnicp_set_initial_mean.argtypes = [vp, dp, dp]
     L.svnicp_set_k.argtypes = [vp, C.c_int]
     L.svnicp_set_max_dist.argtypes = [vp, C.c_double]

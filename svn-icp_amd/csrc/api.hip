@@ -48,6 +48,7 @@ struct svnicp_ctx {
   int64_t B = 0, M = 0, Mp = 0;
   int K = 0, S = 0, P = 0;
   int p_lo = 0, p_hi = 0;
+  bool src_set = false, tgt_set = false;
   bool clouds_set = false, particles_set = false, particles_dirty = false, shard_set = false;
   bool began = false, have_candidates = false, have_result = false;
   Pose0 pose0{};
@@ -234,22 +235,46 @@ int svnicp_synchronize(svnicp_ctx* c) {
   return SVNICP_OK;
 }
 
+int svnicp_set_source(svnicp_ctx* c, const double* src, int64_t B, int mem_kind) {
+  CTX_CHECK(c);
+  if (!src || B < 1) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_source: need B >= 1");
+  if (B > 0x7fffffffLL) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_source: cloud too large");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, c->src.ensure((size_t)B * 3));
+  const hipMemcpyKind kind = mem_kind == SVNICP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(c, hipMemcpyAsync(c->src.p, src, (size_t)B * 24, kind, c->stream));
+  if (mem_kind != SVNICP_MEM_DEVICE) HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse its host buffer
+  c->B = B;
+  c->src_set = true;
+  c->clouds_set = c->src_set && c->tgt_set;
+  c->have_candidates = false;
+  return SVNICP_OK;
+}
+
+int svnicp_set_target(svnicp_ctx* c, const double* tgt, int64_t M, int mem_kind) {
+  CTX_CHECK(c);
+  if (!tgt || M < 1) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_target: need M >= 1");
+  if (M > 0x7fffffffLL) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_target: cloud too large");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, c->tgt.ensure((size_t)M * 3));
+  const hipMemcpyKind kind = mem_kind == SVNICP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(c, hipMemcpyAsync(c->tgt.p, tgt, (size_t)M * 24, kind, c->stream));
+  if (mem_kind != SVNICP_MEM_DEVICE) HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->M = M; c->Mp = knn_padded_targets(M);
+  c->target_layout = -1;  // the SoA copies are (re)built in svnicp_align_begin, once K is final
+  c->tgt_set = true;
+  c->clouds_set = c->src_set && c->tgt_set;
+  c->have_candidates = false;
+  return SVNICP_OK;
+}
+
 int svnicp_set_clouds(svnicp_ctx* c, const double* src, int64_t B, const double* tgt, int64_t M, int mem_kind) {
   CTX_CHECK(c);
   if (!src || !tgt || B < 1 || M < 1) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_clouds: need B >= 1, M >= 1");
   if (M > 0x7fffffffLL || B > 0x7fffffffLL) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_clouds: cloud too large");
-  if (bind(c)) return SVNICP_ERR_HIP;
-  HIPCHK(c, c->src.ensure((size_t)B * 3));
-  HIPCHK(c, c->tgt.ensure((size_t)M * 3));
-  const hipMemcpyKind kind = mem_kind == SVNICP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  HIPCHK(c, hipMemcpyAsync(c->src.p, src, (size_t)B * 24, kind, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->tgt.p, tgt, (size_t)M * 24, kind, c->stream));
-  c->B = B; c->M = M; c->Mp = knn_padded_targets(M);
-  c->target_layout = -1;  // the SoA copies are (re)built in svnicp_align_begin, once K is final
-  if (mem_kind != SVNICP_MEM_DEVICE) HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse its host buffers
-  c->clouds_set = true;
-  c->have_candidates = false;
-  return SVNICP_OK;
+  int rc = svnicp_set_source(c, src, B, mem_kind);
+  if (rc) return rc;
+  return svnicp_set_target(c, tgt, M, mem_kind);
 }
 
 int svnicp_set_particles(svnicp_ctx* c, const double* init, int P) {

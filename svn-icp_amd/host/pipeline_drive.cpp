@@ -2,7 +2,7 @@
 // dumps, per scan, what the pipeline handed to the solver and what it got back.  Used by tests/test_pipeline_gpu.py, which
 // replays the dumped solver inputs through the CPU oracle and through svn-icp_amd/pipeline.py.
 //   g++ -std=c++17 -I include -I svn-icp_amd/host pipeline_drive.cpp -L svn-icp_amd -lsvnicp_hip -o pipeline_drive
-//   pipeline_drive scans.bin out.bin P iterations knn voxel [particles.bin]
+//   pipeline_drive scans.bin out.bin P iterations knn voxel [particles.bin|-] [gpu_map 0|1]
 // scans.bin : int32 n_scans, then per scan { f64 stamp, int32 n, n x 3 float32 }
 // particles : optional f64 [n_scans][6][P] (otherwise the built-in uniform prior sampler)
 // out.bin   : per scan { int32 aligned, f64 pose[12], guess[12], corr[6], var[6], cov[36], int64 B, M, f64 src[3B], tgt[3M], init[6P] }
@@ -26,7 +26,8 @@ int main(int argc, char** argv) {
   cfg.solver.lr = 1.0; cfg.solver.max_dist = 1.0; cfg.solver.SVN_full_grad = false;
   cfg.voxel_size = cfg.map_voxel_size = atof(argv[6]);
   cfg.min_range = 1.0; cfg.max_range = 80.0; cfg.map_range = 100.0; cfg.map_voxel_max_points = 20;
-  FILE* fp = argc > 7 ? fopen(argv[7], "rb") : nullptr;
+  FILE* fp = (argc > 7 && argv[7][0] != '-') ? fopen(argv[7], "rb") : nullptr;
+  cfg.gpu_map = argc > 8 && atoi(argv[8]) != 0;
   try {
     svnicp::RegistrationPipeline pipe(cfg);
     svnicp::Tap tap;
@@ -56,8 +57,8 @@ int main(int argc, char** argv) {
       wr(fo, tap.source.data(), tap.source.size()); wr(fo, tap.target.data(), tap.target.size());
       tap.particles.resize((size_t)6 * cfg.particle_count, 0.0);
       wr(fo, tap.particles.data(), tap.particles.size());
-      printf("scan %d: aligned %d  B %lld  M %lld  voxels %zu  pose t = %.4f %.4f %.4f\n", s, aligned, (long long)B, (long long)M,
-             pipe.map().Size(), r.pose.t[0], r.pose.t[1], r.pose.t[2]);
+      printf("scan %d: aligned %d  B %lld  M %lld  voxels %zu  h2d bytes so far %zu  pose t = %.4f %.4f %.4f\n", s, aligned, (long long)B,
+             (long long)M, pipe.map_voxels(), pipe.bytes_h2d(), r.pose.t[0], r.pose.t[1], r.pose.t[2]);
     }
   } catch (const std::exception& e) {
     fprintf(stderr, "svnicp: %s\n", e.what());

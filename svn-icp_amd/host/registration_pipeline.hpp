@@ -218,6 +218,38 @@ class VoxelHashMap {
   std::map<Key, Cloud> map_;
 };
 
+// The same map resident in HBM (svnicp_map_* of the C ABI, csrc/voxel_map.hip): AddPointCloud uploads only the new points, a
+// query leaves float64 rows in device memory for SVNICP::add_cloud_device_target.  Same voxel order as the host map above.
+class DeviceVoxelMap {
+ public:
+  DeviceVoxelMap(double voxel_size, double max_range, int max_points, int device = 0) {
+    if (svnicp_map_create(device, voxel_size, max_range, max_points, 0, &m_) != 0) throw std::runtime_error(svnicp_map_last_error(nullptr));
+  }
+  ~DeviceVoxelMap() { svnicp_map_destroy(m_); }
+  DeviceVoxelMap(const DeviceVoxelMap&) = delete;
+  DeviceVoxelMap& operator=(const DeviceVoxelMap&) = delete;
+  bool Empty() { return Size() == 0; }
+  size_t Size() { int64_t n = 0; chk(svnicp_map_size(m_, &n)); return (size_t)n; }
+  void AddPointCloud(const Cloud& cloud, const Pose3& pose) {
+    chk(svnicp_map_add_cloud(m_, cloud.empty() ? nullptr : &cloud[0][0], (int64_t)cloud.size(), SVNICP_MEM_HOST, pose.R.data(), pose.t.data()));
+  }
+  // -> number of points; the rows are at points_devptr()
+  int64_t GetMap(const Pose3& pose, double max_range) { int64_t n = 0; chk(svnicp_map_query(m_, pose.t.data(), max_range, &n)); return n; }
+  int64_t GetMap() { int64_t n = 0; chk(svnicp_map_query(m_, nullptr, -1.0, &n)); return n; }
+  const double* points_devptr() { return static_cast<const double*>(svnicp_map_points_devptr(m_)); }
+  std::vector<double> download() {
+    int64_t n = 0;
+    chk(svnicp_map_download(m_, nullptr, 0, &n));
+    std::vector<double> o((size_t)3 * n);
+    if (n) chk(svnicp_map_download(m_, o.data(), n, &n));
+    return o;
+  }
+
+ private:
+  void chk(int rc) { if (rc != 0) throw std::runtime_error(svnicp_map_last_error(m_)); }
+  svnicp_map* m_ = nullptr;
+};
+
 // ------------------------------------------------------------------------------------------------ prediction
 // OdometryPipeline::pose_prediction (:706-737): constant twist between the last two poses scaled by the time ratio;
 // identity / last pose while fewer than two poses exist
@@ -243,6 +275,7 @@ struct PipelineConfig {  // field names follow the node's parameters (OdometryPi
   SteinICPParam solver;
   uint64_t seed = 0;
   int device = 0;
+  bool gpu_map = false;  // keep the local map in HBM (DeviceVoxelMap): the target never crosses PCIe
 };
 
 struct ScanResult {
@@ -266,12 +299,16 @@ constexpr double kPriorUb[6] = {0.3, 0.2, 0.1, 0.004, 0.004, 0.012};
 class RegistrationPipeline {
  public:
   explicit RegistrationPipeline(const PipelineConfig& cfg)
-      : cfg_(cfg), map_(cfg.map_voxel_size, cfg.map_range, cfg.map_voxel_max_points), rng_(cfg.seed * 0x9e3779b97f4a7c15ull + 0x2545f4914f6cdd1dull) {}
+      : cfg_(cfg), map_(cfg.map_voxel_size, cfg.map_range, cfg.map_voxel_max_points), rng_(cfg.seed * 0x9e3779b97f4a7c15ull + 0x2545f4914f6cdd1dull) {
+    if (cfg.gpu_map) dmap_ = std::make_unique<DeviceVoxelMap>(cfg.map_voxel_size, cfg.map_range, cfg.map_voxel_max_points, cfg.device);
+  }
 
   // replaces the built-in uniform prior sampler (svnicp::initialize_particles, ICPUtils.cpp:45-58): fills [6][P] row-major
   void set_particle_source(std::function<void(int, double*)> f) { particle_source_ = std::move(f); }
   void set_tap(Tap* t) { tap_ = t; }
   const VoxelHashMap& map() const { return map_; }
+  size_t map_voxels() { return dmap_ ? dmap_->Size() : map_.Size(); }
+  size_t bytes_h2d() const { return bytes_h2d_; }   // cloud bytes sent to the GPU so far (source scans + map traffic)
   const std::vector<Pose3>& poses() const { return poses_; }
 
   // one pass of ICP_processing's loop body for one LiDAR frame (points: n x 3 float32, sensor frame)
@@ -284,17 +321,28 @@ class RegistrationPipeline {
     const Pose3 guess = pose_prediction(poses_, times_, stamp);                                        // :563-564
     std::vector<double> init = sample_particles();                                                     // :573
     res.initial_guess = guess;
-    if (map_.Empty()) {                                                                                // :585-593
-      map_.AddPointCloud(cropped, guess);
+    if (dmap_ ? dmap_->Empty() : map_.Empty()) {                                                       // :585-593
+      if (dmap_) { dmap_->AddPointCloud(cropped, guess); bytes_h2d_ += cropped.size() * 12; } else map_.AddPointCloud(cropped, guess);
       poses_.push_back(guess); times_.push_back(stamp);
       res.pose = guess;
       return res;
     }
-    Cloud target = map_.GetMap(guess, scan_max_range_ + 10.0);                                         // :577-578
-    if (target.empty()) target = map_.GetMap();                                                        // :579-581
-    const std::vector<double> src64 = widen(source), tgt64 = widen(target);                            // ICPUtils.cpp:27-43
+    const std::vector<double> src64 = widen(source);                                                   // ICPUtils.cpp:27-43
     if (!solver_) solver_ = std::make_unique<SVNICP>(cfg_.solver, init, ParticleWeightOpt{}, cfg_.device);
-    solver_->add_cloud(src64.data(), (int64_t)source.size(), tgt64.data(), (int64_t)target.size(), init.data(), cfg_.particle_count);  // :582
+    std::vector<double> tgt64;
+    if (dmap_) {
+      int64_t M = dmap_->GetMap(guess, scan_max_range_ + 10.0);                                        // :577-578
+      if (M == 0) M = dmap_->GetMap();                                                                 // :579-581
+      solver_->add_cloud_device_target(src64.data(), (int64_t)source.size(), dmap_->points_devptr(), M, init.data(), cfg_.particle_count);
+      bytes_h2d_ += src64.size() * 8;
+      if (tap_) tgt64 = dmap_->download();
+    } else {
+      Cloud target = map_.GetMap(guess, scan_max_range_ + 10.0);                                       // :577-578
+      if (target.empty()) target = map_.GetMap();                                                      // :579-581
+      tgt64 = widen(target);
+      solver_->add_cloud(src64.data(), (int64_t)source.size(), tgt64.data(), (int64_t)target.size(), init.data(), cfg_.particle_count);  // :582
+      bytes_h2d_ += (src64.size() + tgt64.size()) * 8;
+    }
     solver_->set_initial_mean(guess.R.data(), guess.t.data());                                         // :598
     if (tap_) { tap_->source = src64; tap_->target = tgt64; tap_->particles = init; tap_->initial_guess = guess; }
     res.state = (int)solver_->stein_align();                                                           // :599
@@ -306,7 +354,7 @@ class RegistrationPipeline {
     res.particles = solver_->get_particles();
     res.weights = solver_->get_particle_weight();
     res.pose = guess * correction_to_pose(res.correction);                                             // updater_, :37-46
-    map_.AddPointCloud(to_map, res.pose);                                                              // :630
+    if (dmap_) { dmap_->AddPointCloud(to_map, res.pose); bytes_h2d_ += to_map.size() * 12; } else map_.AddPointCloud(to_map, res.pose);  // :630
     poses_.push_back(res.pose); times_.push_back(stamp);
     return res;
   }
@@ -344,6 +392,8 @@ class RegistrationPipeline {
   std::function<void(int, double*)> particle_source_;
   Tap* tap_ = nullptr;
   std::unique_ptr<SVNICP> solver_;
+  std::unique_ptr<DeviceVoxelMap> dmap_;
+  size_t bytes_h2d_ = 0;
 };
 
 }  // namespace svnicp

@@ -124,6 +124,94 @@ def downsample_uniform(points: np.ndarray, radius: float) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------- local map
+def transform_f32(cloud, T) -> np.ndarray:
+    """pcl::transformPointCloud on float32 points: q = ((R0·x + R1·y) + R2·z) + t per component, every step rounded to
+    float32 — the same order as registration_pipeline.hpp and voxel_map.hip, so all three maps hold identical points."""
+    c = np.asarray(cloud, np.float32)
+    R = np.asarray(T, float)[:3, :3].astype(np.float32)
+    t = np.asarray(T, float)[:3, 3].astype(np.float32)
+    out = np.empty((c.shape[0], 3), np.float32)
+    for d in range(3):
+        out[:, d] = ((R[d, 0] * c[:, 0] + R[d, 1] * c[:, 1]) + R[d, 2] * c[:, 2]) + t[d]
+    return out
+
+
+class DeviceVoxelHashMap:
+    """The same map resident in HBM (svnicp_map_* of the C ABI, csrc/voxel_map.hip): ``add_pointcloud`` uploads only the new
+    points, ``get_map`` leaves the selected points in device memory as float64 rows and returns (device pointer, count) for
+    ``SVNICP.add_cloud_device_target``.  Voxels come out in ascending (x, y, z) index, points of a voxel in insertion order."""
+
+    def __init__(self, voxel_size: float, max_range: float, max_points: int, device: int = 0, capacity_voxels: int = 0):
+        import ctypes as C
+        from . import binding
+        self._C = C
+        self._L = binding.load_library()
+        self._h = C.c_void_p()
+        rc = self._L.svnicp_map_create(int(device), float(voxel_size), float(max_range), int(max_points), int(capacity_voxels),
+                                       C.byref(self._h))
+        if rc != 0:
+            raise binding.SvnIcpError(f"svnicp_map_create failed ({rc}): {self._L.svnicp_map_last_error(None).decode()}")
+        self.bytes_uploaded = 0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            from . import binding
+            raise binding.SvnIcpError(f"{what} failed ({rc}): {self._L.svnicp_map_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.svnicp_map_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = self._C.c_int64(0)
+        self._chk(self._L.svnicp_map_size(self._h, self._C.byref(n)), "svnicp_map_size")
+        return int(n.value)
+
+    def empty(self) -> bool:
+        return len(self) == 0
+
+    def add_pointcloud(self, cloud: np.ndarray, pose: np.ndarray):
+        C = self._C
+        pts = np.ascontiguousarray(np.asarray(cloud, np.float32)[:, :3])
+        T = np.asarray(pose, float)
+        R = np.ascontiguousarray(T[:3, :3]).reshape(9)
+        t = np.ascontiguousarray(T[:3, 3])
+        dp = C.POINTER(C.c_double)
+        self._chk(self._L.svnicp_map_add_cloud(self._h, pts.ctypes.data_as(C.c_void_p), pts.shape[0], 0, R.ctypes.data_as(dp),
+                                               t.ctypes.data_as(dp)), "svnicp_map_add_cloud")
+        self.bytes_uploaded += pts.nbytes
+
+    def get_map(self, pose=None, max_range: float | None = None):
+        """-> (device pointer of float64 [M][3], M)"""
+        C = self._C
+        n = C.c_int64(0)
+        if pose is None:
+            self._chk(self._L.svnicp_map_query(self._h, None, -1.0, C.byref(n)), "svnicp_map_query")
+        else:
+            c = np.ascontiguousarray(np.asarray(pose, float)[:3, 3])
+            self._chk(self._L.svnicp_map_query(self._h, c.ctypes.data_as(C.POINTER(C.c_double)), float(max_range), C.byref(n)),
+                      "svnicp_map_query")
+        return int(self._L.svnicp_map_points_devptr(self._h) or 0), int(n.value)
+
+    def download(self) -> np.ndarray:
+        """The rows of the last get_map as a host array (test tap)."""
+        C = self._C
+        n = C.c_int64(0)
+        self._chk(self._L.svnicp_map_download(self._h, None, 0, C.byref(n)), "svnicp_map_download")
+        out = np.zeros((int(n.value), 3))
+        if out.size:
+            self._chk(self._L.svnicp_map_download(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.shape[0], C.byref(n)),
+                      "svnicp_map_download")
+        return out
+
+
 class VoxelHashMap:
     """svnicp::VoxelHashMap (src/core/VoxelHashMap.cpp:22-101): voxel -> at most ``max_points`` points, in insertion
     order; voxel index = coordinates / voxel_size truncated TOWARD ZERO (Eigen ``cast<int>``, :29); a voxel is dropped
@@ -144,7 +232,7 @@ class VoxelHashMap:
 
     def add_pointcloud(self, cloud: np.ndarray, pose: np.ndarray):
         T = np.asarray(pose, float)
-        pts = (np.asarray(cloud, np.float32) @ T[:3, :3].T.astype(np.float32) + T[:3, 3].astype(np.float32)).astype(np.float32)
+        pts = transform_f32(cloud, T)
         idx = np.trunc(pts / np.float32(self.voxel_size)).astype(np.int64)
         # group by voxel, keeping the input order inside a voxel
         order = np.lexsort((np.arange(idx.shape[0]), idx[:, 2], idx[:, 1], idx[:, 0]))
@@ -211,6 +299,7 @@ class PipelineConfig:
     map_voxel_max_points: int = 20
     map_range: float = 100.0
     particle_count: int = 128
+    gpu_map: bool = False          # keep the local map in HBM (DeviceVoxelHashMap): the target never crosses PCIe
     solver: SteinICPParam = field(default_factory=lambda: SteinICPParam(iterations=20, lr=1.0, max_dist=1.0, KNN_count=100))
     seed: int = 0
 
@@ -236,7 +325,10 @@ class RegistrationPipeline:
     def __init__(self, cfg: PipelineConfig | None = None, device: int = 0):
         self.cfg = cfg or PipelineConfig()
         self.device = device
-        self.map = VoxelHashMap(self.cfg.map_voxel_size, self.cfg.map_range, self.cfg.map_voxel_max_points)
+        self.map = (DeviceVoxelHashMap(self.cfg.map_voxel_size, self.cfg.map_range, self.cfg.map_voxel_max_points, device)
+                    if self.cfg.gpu_map else
+                    VoxelHashMap(self.cfg.map_voxel_size, self.cfg.map_range, self.cfg.map_voxel_max_points))
+        self.bytes_h2d = 0            # cloud bytes sent to the GPU so far (source scans + map traffic)
         self.poses: list[np.ndarray] = []
         self.times: list[float] = []
         self.scan_max_range = 0.0
@@ -258,13 +350,21 @@ class RegistrationPipeline:
             self.map.add_pointcloud(cropped, guess)
             self.poses.append(guess); self.times.append(stamp)
             return ScanResult(stamp, guess, guess, preprocessing_s=time.perf_counter() - t0)
-        target = self.map.get_map(guess, self.scan_max_range + 10.0)                                            # :577-578
-        if target.shape[0] == 0:
-            target = self.map.get_map()                                                                         # :579-581
         if self._solver is None:
             self._solver = SVNICP(c.solver, init, ParticleWeightOpt(), device=self.device)
         s = self._solver
-        s.add_cloud(source, target, init)                                                                       # :583
+        if c.gpu_map:
+            ptr, M = self.map.get_map(guess, self.scan_max_range + 10.0)                                        # :577-578
+            if M == 0:
+                ptr, M = self.map.get_map()                                                                     # :579-581
+            s.add_cloud_device_target(source, ptr, M, init)                                                     # :583
+            self.bytes_h2d += source.shape[0] * 24
+        else:
+            target = self.map.get_map(guess, self.scan_max_range + 10.0)                                        # :577-578
+            if target.shape[0] == 0:
+                target = self.map.get_map()                                                                     # :579-581
+            s.add_cloud(source, target, init)                                                                   # :583
+            self.bytes_h2d += (source.shape[0] + target.shape[0]) * 24
         t1 = time.perf_counter()
         s.set_initial_mean(guess)                                                                               # :601
         state = s.stein_align()                                                                                 # :602
@@ -275,6 +375,8 @@ class RegistrationPipeline:
         res = ScanResult(stamp, pose, guess, corr, s.get_distribution(), s.get_cov_matrix(), s.get_particles().reshape(-1),
                          s.get_particle_weight(), t1 - t0, 0.0, int(state))
         self.map.add_pointcloud(to_map, pose)                                                                   # :627
+        if c.gpu_map:
+            self.bytes_h2d += to_map.shape[0] * 12
         self.poses.append(pose); self.times.append(stamp)                                                       # :630
         res.align_s = time.perf_counter() - t1
         return res

@@ -155,6 +155,19 @@ class _SolverBase:
         self._check(self._L.svnicp_set_particles(self._h, init.ctypes.data_as(C.POINTER(C.c_double)), self._P),
                     "svnicp_set_particles")
 
+    def add_cloud_device_target(self, new_cloud, target_devptr: int, M: int, init_pose):
+        """add_cloud with a host source scan and a target that already lives in HBM (DeviceVoxelHashMap.get_map):
+        the source goes over PCIe, the target is copied device-to-device."""
+        src = np.ascontiguousarray(np.asarray(new_cloud, np.float64).reshape(-1, 3))
+        self._check(self._L.svnicp_set_source(self._h, src.ctypes.data_as(C.c_void_p), src.shape[0], 0), "svnicp_set_source")
+        self._check(self._L.svnicp_set_target(self._h, C.c_void_p(int(target_devptr)), int(M), 1), "svnicp_set_target")
+        self._check(self._L.svnicp_synchronize(self._h), "svnicp_synchronize")
+        self._B, self._M = src.shape[0], int(M)
+        init = self._pose_arg(init_pose)
+        self._P = init.shape[1]
+        self._check(self._L.svnicp_set_particles(self._h, init.ctypes.data_as(C.POINTER(C.c_double)), self._P),
+                    "svnicp_set_particles")
+
     def set_initial_mean(self, pose):
         """SVGDICP::set_initial_mean(gtsam::Pose3) (include/core/SVGDICP.h:102-110).
         ``pose``: 4x4 homogeneous matrix, or a (R[3,3], t[3]) pair."""

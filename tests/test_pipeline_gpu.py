@@ -83,22 +83,33 @@ def test_cpp_registration_pipeline_against_oracle_and_python(hip, orc, tmp_path)
     r = subprocess.run([exe, str(tmp_path / "scans.bin"), str(tmp_path / "out.bin"), str(P), str(I), str(K), str(voxel),
                         str(tmp_path / "particles.bin")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    raw = open(tmp_path / "out.bin", "rb").read()
-    off = 0
+    def parse(path):
+        raw = open(path, "rb").read()
+        off = 0
 
-    def take(fmt_dtype, n):
-        nonlocal off
-        a = np.frombuffer(raw, fmt_dtype, n, off); off += a.nbytes
-        return a
-    recs = []
-    for k in range(n_scans):
-        aligned = int(take("<i4", 1)[0])
-        pose, guess = take("<f8", 12), take("<f8", 12)
-        corr, var, cov = take("<f8", 6), take("<f8", 6), take("<f8", 36)
-        B, M = (int(v) for v in take("<i8", 2))
-        src, tgt, init = take("<f8", 3 * B).reshape(B, 3), take("<f8", 3 * M).reshape(M, 3), take("<f8", 6 * P).reshape(6, P)
-        recs.append(dict(aligned=aligned, pose=pose, guess=guess, corr=corr, var=var, cov=cov, src=src, tgt=tgt, init=init))
-    assert off == len(raw) and recs[0]["aligned"] == 0 and all(rc["aligned"] == 1 for rc in recs[1:])
+        def take(fmt_dtype, n):
+            nonlocal off
+            a = np.frombuffer(raw, fmt_dtype, n, off); off += a.nbytes
+            return a
+        recs = []
+        for k in range(n_scans):
+            aligned = int(take("<i4", 1)[0])
+            pose, guess = take("<f8", 12), take("<f8", 12)
+            corr, var, cov = take("<f8", 6), take("<f8", 6), take("<f8", 36)
+            B, M = (int(v) for v in take("<i8", 2))
+            src, tgt, init = take("<f8", 3 * B).reshape(B, 3), take("<f8", 3 * M).reshape(M, 3), take("<f8", 6 * P).reshape(6, P)
+            recs.append(dict(aligned=aligned, pose=pose, guess=guess, corr=corr, var=var, cov=cov, src=src, tgt=tgt, init=init))
+        assert off == len(raw) and recs[0]["aligned"] == 0 and all(rc["aligned"] == 1 for rc in recs[1:])
+        return recs
+    recs = parse(tmp_path / "out.bin")
+    # the same drive with the local map resident in HBM (DeviceVoxelMap): the very same target rows reach the solver
+    r2 = subprocess.run([exe, str(tmp_path / "scans.bin"), str(tmp_path / "out_gpu.bin"), str(P), str(I), str(K), str(voxel),
+                         str(tmp_path / "particles.bin"), "1"], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    for a_, b_ in zip(recs, parse(tmp_path / "out_gpu.bin")):
+        assert np.array_equal(a_["tgt"], b_["tgt"]) and np.array_equal(a_["src"], b_["src"])
+        assert np.array_equal(a_["pose"], b_["pose"]) and np.array_equal(a_["cov"], b_["cov"])
+    print(r.stdout.splitlines()[-1]); print(r2.stdout.splitlines()[-1])
 
     def mat(p12):
         T = np.eye(4); T[:3, :3] = p12[:9].reshape(3, 3); T[:3, 3] = p12[9:]

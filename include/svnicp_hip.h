@@ -121,6 +121,12 @@ int svnicp_get_particle_weight(svnicp_ctx *ctx, double *outP);       /* SVNICP.c
 int svnicp_get_particle_history(svnicp_ctx *ctx, float *outIx6P);    /* SVGDICP.cpp:526-534: I rows of 6P float32 */
 int svnicp_get_runtime(svnicp_ctx *ctx, double out3[3]);             /* SVGDICP.h:94-96 {knn_s, update_s, finish_iter} */
 
+/* test / profiling knobs of a context, by name (the product configuration is the default of every one):
+ *   knn = auto|v1|v2        fallback_sliced_max = <n>      accum = split|mfma|valu|f64      search = bf16|f32
+ *   update = auto|fused     fused_update_max_p = <P>       wgpcu = <search>,<accumulate>     tp = <points>    debug = 0|1
+ * The environment variable SVNICP_OPTIONS ("name=value;name=value") is read once, in svnicp_create. */
+int svnicp_set_option(svnicp_ctx *ctx, const char *name, const char *value);
+
 /* ---- split-phase entry points: one process per GPU, particles sharded across ranks ----------
  * (new functionality; the reference is single-GPU).  Sequence per registration:
  *   svnicp_set_shard -> svnicp_stage_candidates(b_lo,b_hi) -> [host all-gathers rows of
@@ -169,6 +175,9 @@ int svnicp_get_candidate_dist2(svnicp_ctx *ctx, double *outBK);
  * phi [I][P][6], h [I] */
 int svnicp_get_trace(svnicp_ctx *ctx, int32_t *corr, double *H, double *b, double *newton,
                      double *phi, double *h);
+/* iterations the last align executed (= iterations unless the early stop fired); svnicp_get_runtime()[2] is the
+ * reference's finish_iter_, which SVN mode never updates */
+int svnicp_get_iterations_run(svnicp_ctx *ctx, int *out);
 /* elapsed GPU milliseconds of the last align, by phase: {stage A (candidates + table),
  * iterations (accumulate + update), total} — measured with hipEvents on the context's stream */
 int svnicp_get_gpu_ms(svnicp_ctx *ctx, double out3[3]);

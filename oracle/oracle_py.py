@@ -72,6 +72,8 @@ def lib():
         L.orc_get_particle_history.argtypes = [C.c_void_p, fp]
         L.orc_get_finish_iter.argtypes = [C.c_void_p]
         L.orc_get_finish_iter.restype = C.c_int
+        L.orc_get_iterations_run.argtypes = [C.c_void_p]
+        L.orc_get_iterations_run.restype = C.c_int
         L.orc_get_candidates.argtypes = [C.c_void_p]
         L.orc_get_candidates.restype = ip64
         L.orc_get_candidate_dist2.argtypes = [C.c_void_p]
@@ -253,7 +255,11 @@ class Solver:
         return out
 
     def finish_iter(self):
+        """finish_iter_ as the reference keeps it: constructor value, changed only by an SVGD early stop."""
         return self.L.orc_get_finish_iter(self.h)
+
+    def iterations_run(self):
+        return self.L.orc_get_iterations_run(self.h)
 
     def candidates(self):
         p = self.L.orc_get_candidates(self.h)

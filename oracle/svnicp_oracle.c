@@ -268,7 +268,8 @@ struct orc_solver {
   double *cand_d2;    /* [B][K] */
   double *cand_xyz;   /* [B][K][3]  target_batch (one copy; the reference makes I identical ones) */
   double *opt_state;  /* SVGD optimizer state: [3][P][6] */
-  int finish_iter;
+  int finish_iter;   /* finish_iter_: set in the constructor (SVGDICP.cpp:42) and by SVGDICP::stein_align's early stop only (:128) */
+  int iters_run;     /* test tap: iterations the last align executed */
   orc_trace tr;
   int has_trace;
 };
@@ -314,6 +315,7 @@ orc_solver *orc_create(int mode, const orc_params *prm, const double *init_pose6
   s->prm = *prm;
   s->K = prm->knn_count;                  /* SVGDICP.cpp:43 */
   s->finish_iter = prm->iterations;       /* SVGDICP.cpp:42 */
+  s->iters_run = 0;
   const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   memcpy(s->R0, I3, sizeof I3);           /* SVGDICP.cpp:38-39 */
   s->t0[0] = s->t0[1] = s->t0[2] = 0;
@@ -622,7 +624,8 @@ static int svn_update(orc_solver *s, int epoch, double *H, double *bv) {
     }
     m /= P;
     /* torch::lt(f64 0-dim, f32 1-dim) computes in float32 (type promotion) */
-    if ((float)m < (float)s->prm.convergence_threshold) { s->finish_iter = epoch + 1; stop = 1; }
+    /* SVNICP::stein_align only breaks (SVNICP.cpp:95-101): finish_iter_ keeps its constructor value */
+    if ((float)m < (float)s->prm.convergence_threshold) { s->iters_run = epoch + 1; stop = 1; }
   }
   if (!stop) {
     refresh_pose_svn(s);                                                      /* :103-106 */
@@ -638,7 +641,7 @@ static int svn_align(orc_solver *s) { /* SVNICP.cpp:41-114 */
   alloc_history(s);
   candidate_stage(s);
   double *H = (double *)malloc((size_t)P * 36 * 8), *bv = (double *)malloc((size_t)P * 6 * 8);
-  s->finish_iter = I;
+  s->iters_run = I;
   for (int epoch = 0; epoch < I; ++epoch) {
     newton_accumulate(s, epoch, H, bv);
     if (svn_update(s, epoch, H, bv)) break;
@@ -653,7 +656,7 @@ static int svn_align(orc_solver *s) { /* SVNICP.cpp:41-114 */
 void orc_sp_begin(orc_solver *s) {
   alloc_history(s);
   candidate_alloc(s);
-  s->finish_iter = s->prm.iterations;
+  s->iters_run = s->prm.iterations;
 }
 void orc_sp_candidate_rows(orc_solver *s, int64_t b_lo, int64_t b_hi) { candidate_rows(s, b_lo, b_hi); }
 int64_t *orc_sp_candidates(orc_solver *s) { return s->cand_idx; }
@@ -784,7 +787,7 @@ static int svgd_align(orc_solver *s) { /* SVGDICP.cpp:66-140 */
   double *g = (double *)malloc((size_t)P * 6 * 8), *phi = (double *)malloc((size_t)P * 6 * 8);
   double *x = (double *)malloc((size_t)P * 6 * 8), *old = (double *)malloc((size_t)P * 6 * 8);
   double *Km = (double *)malloc((size_t)P * P * 8);
-  s->finish_iter = I;
+  s->iters_run = I;   /* finish_iter_ is NOT reset here: it keeps the last early stop's value (SVGDICP.cpp:42,128) */
   for (int epoch = 0; epoch < I; ++epoch) {
     for (int p = 0; p < P; ++p) {                                            /* :88-89 */
       const double *eu = s->eul + 6 * p;
@@ -823,7 +826,7 @@ static int svgd_align(orc_solver *s) { /* SVGDICP.cpp:66-140 */
         m += sqrt(n2);
       }
       m /= P;
-      if ((float)m < (float)s->prm.convergence_threshold) { s->finish_iter = epoch + 1; break; }
+      if ((float)m < (float)s->prm.convergence_threshold) { s->finish_iter = epoch + 1; s->iters_run = epoch + 1; break; }
     }
     for (int i = 0; i < 6 * P; ++i) s->history[(size_t)epoch * 6 * P + i] = (float)s->pose[i]; /* :133 */
     if (s->has_trace && s->tr.pose) memcpy(s->tr.pose + (size_t)epoch * 6 * P, s->pose, (size_t)6 * P * 8);
@@ -899,5 +902,6 @@ void orc_get_particle_history(orc_solver *s, float *out) {
   if (s->history) memcpy(out, s->history, (size_t)s->hist_I * 6 * s->P * sizeof(float));
 }
 int orc_get_finish_iter(orc_solver *s) { return s->finish_iter; }
+int orc_get_iterations_run(orc_solver *s) { return s->iters_run; }
 const int64_t *orc_get_candidates(orc_solver *s) { return s->cand_idx; }
 const double *orc_get_candidate_dist2(orc_solver *s) { return s->cand_d2; }

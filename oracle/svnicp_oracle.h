@@ -95,7 +95,8 @@ void orc_get_cov_matrix(orc_solver *s, double out[36]);         /* SVNICP.cpp:29
 void orc_get_particles(orc_solver *s, double *out6P);           /* SVGDICP.cpp:515-520 */
 void orc_get_particle_weight(orc_solver *s, double *outP);      /* SVNICP.cpp:281-284 */
 void orc_get_particle_history(orc_solver *s, float *outIx6P);   /* SVGDICP.cpp:526-534 */
-int orc_get_finish_iter(orc_solver *s);
+int orc_get_finish_iter(orc_solver *s);      /* finish_iter_ as the reference keeps it (SVGDICP.cpp:42,128) */
+int orc_get_iterations_run(orc_solver *s);   /* test tap: iterations the last align executed */
 /* candidate indices of the last align: [B][K] int64 (sourceKNN_idx_, SVGDICP.cpp:214) */
 const int64_t *orc_get_candidates(orc_solver *s);
 const double *orc_get_candidate_dist2(orc_solver *s);

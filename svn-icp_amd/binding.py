@@ -85,6 +85,7 @@ def load_library():
     L.svnicp_map_download.argtypes = [vp, dp, C.c_int64, C.POINTER(C.c_int64)]
     L.svnicp_set_initial_mean.argtypes = [vp, dp, dp]
     L.svnicp_set_k.argtypes = [vp, C.c_int]
+    L.svnicp_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.svnicp_set_max_dist.argtypes = [vp, C.c_double]
     L.svnicp_align.argtypes = [vp]
     L.svnicp_align_async.argtypes = [vp]
@@ -98,6 +99,7 @@ def load_library():
     L.svnicp_get_knn_survivors.argtypes = [vp, ip]
     L.svnicp_get_knn_fallback_rows.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_int)]
     L.svnicp_get_ambiguous_steps.argtypes = [vp, C.POINTER(C.c_int)]
+    L.svnicp_get_iterations_run.argtypes = [vp, C.POINTER(C.c_int)]
     L.svnicp_set_profile.argtypes = [vp, C.c_int]
     L.svnicp_get_kernel_ms.argtypes = [vp, dp, ip]
     L.svnicp_set_shard.argtypes = [vp, C.c_int, C.c_int]

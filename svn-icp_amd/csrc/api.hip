@@ -83,6 +83,10 @@ struct svnicp_ctx {
   DevBuf<float> history;
   DevBuf<int> ctl;
   int hist_I = 0, hist_P = 0;
+  Tuning tune{};
+  unsigned long long* dbg_phase = nullptr;   // debug option: per-phase wave cycles of k_knn_tiles (per context, per device)
+  unsigned long long* dbg_upd = nullptr;     // debug option: phase cycles of k_particle_update
+  int finish_iter = 0;   // finish_iter_: constructor value, changed only by an SVGD-mode early stop (SVGDICP.cpp:42,128)
   double gpu_ms[3] = {0, 0, 0};
   bool timing_valid = false;
   // optional per-kernel-class timing (svnicp_set_profile): event pairs around every launch
@@ -94,15 +98,8 @@ struct svnicp_ctx {
   size_t pused = 0;
 };
 
-constexpr int kFusedUpdateMaxP = 128;  // measured crossover (C3: equal, P=256: 4.5x); above this the Stein step runs as workgroup-parallel kernels
-static int fused_update_max_p() {         // A/B switch for tests and profiling: SVNICP_FUSED_UPDATE_MAXP=<P>
-  static const int v = [] {
-    const char* e = getenv("SVNICP_FUSED_UPDATE_MAXP");
-    const int x = e ? atoi(e) : kFusedUpdateMaxP;
-    return x < 1 ? 1 : (x > 700 ? 700 : x);  // P = 1 has no pair statistics; the fused kernel's LDS ends near P = 800
-  }();
-  return v;
-}
+// Tuning::fused_update_max_p default 128: measured crossover (C3: equal, P=256: 4.5x); above it the Stein step runs as
+// workgroup-parallel kernels
 constexpr int kFallbackGrid = 256;  // workgroups of the streaming kernel when it only redoes failed queries
 constexpr int kFallbackSlicedMax = 512;  // up to this many failed queries are redone by target slices (all CUs per query)
 constexpr int kFallbackQW = 2;      // … two queries per wave, so a few hundred failures still run in parallel
@@ -184,6 +181,7 @@ int svnicp_create(const svnicp_params* params, int device, const double* init_po
   c->device = device;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->K = params->knn_count;
+  c->finish_iter = params->iterations;
   const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   std::memcpy(c->pose0.R0, I3, sizeof I3);  // SVGDICP.cpp:38-39
   c->pose0.t0[0] = c->pose0.t0[1] = c->pose0.t0[2] = 0.0;
@@ -196,6 +194,19 @@ int svnicp_create(const svnicp_params* params, int device, const double* init_po
     if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(nullptr, SVNICP_ERR_HIP, "hipEventCreate failed"); }
   if (c->ctl.ensure(4) != hipSuccess) { delete c; return fail(nullptr, SVNICP_ERR_NOMEM, "hipMalloc failed"); }
   *out = c;
+  if (const char* e = getenv("SVNICP_OPTIONS")) {   // read ONCE, at creation: "name=value,name=value" for profiling scripts
+    std::string all(e);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      const size_t end = all.find(';', pos) == std::string::npos ? all.size() : all.find(';', pos);
+      const std::string kv = all.substr(pos, end - pos);
+      const size_t eq = kv.find('=');
+      if (eq != std::string::npos && svnicp_set_option(c, kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str()) != 0) {
+        g_create_error = c->err; svnicp_destroy(c); *out = nullptr; return SVNICP_ERR_INVALID;
+      }
+      pos = end + 1;
+    }
+  }
   if (init_pose6xP) {
     int rc = svnicp_set_particles(c, init_pose6xP, P);
     if (rc != 0) { g_create_error = c->err; svnicp_destroy(c); *out = nullptr; return rc; }
@@ -214,6 +225,8 @@ void svnicp_destroy(svnicp_ctx* c) {
   c->eul.release(); c->opt.release(); c->uctl.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
   c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->tail.release(); c->kbest.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  if (c->dbg_phase) (void)hipFree(c->dbg_phase);
+  if (c->dbg_upd) (void)hipFree(c->dbg_upd);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->pev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -329,6 +342,30 @@ int svnicp_set_max_dist(svnicp_ctx* c, double md) {
   return SVNICP_OK;
 }
 
+int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
+  CTX_CHECK(c);
+  if (!name || !value) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: null argument");
+  const std::string k(name), v(value);
+  Tuning& t = c->tune;
+  auto num = [&](int lo, int hi, int* out) { char* end = nullptr; const long x = strtol(v.c_str(), &end, 10);
+                                             if (end == v.c_str() || *end || x < lo || x > hi) return false; *out = (int)x; return true; };
+  bool ok = true;
+  if (k == "knn") { if (v == "auto") t.knn = -1; else if (v == "v1") t.knn = 0; else if (v == "v2") t.knn = 1; else ok = false; }
+  else if (k == "fallback_sliced_max") ok = num(-1, 1 << 20, &t.fallback_sliced_max);
+  else if (k == "accum") { if (v == "f64") t.accum = 0; else if (v == "valu") t.accum = 1; else if (v == "mfma") t.accum = 2; else if (v == "split") t.accum = 3; else ok = false; }
+  else if (k == "search") { if (v == "bf16") t.search_f32 = 0; else if (v == "f32") t.search_f32 = 1; else ok = false; }
+  else if (k == "update") { if (v == "auto") t.update_fused = 0; else if (v == "fused") t.update_fused = 1; else ok = false; }
+  else if (k == "fused_update_max_p") ok = num(1, 700, &t.fused_update_max_p);   // P = 1 has no pair statistics; the fused kernel's LDS ends near P = 800
+  else if (k == "wgpcu") { int x = 0, y = 0; ok = sscanf(v.c_str(), "%d,%d", &x, &y) == 2 && x >= 0 && x <= 16 && y >= 0 && y <= 16; if (ok) { t.wgpcu_search = x; t.wgpcu_accum = y; } }
+  else if (k == "tp") ok = num(0, 1 << 16, &t.tp);
+  else if (k == "debug") ok = num(0, 1, &t.debug);
+  else return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: unknown option '" + k + "'");
+  if (!ok) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: bad value '" + v + "' for option '" + k + "'");
+  c->have_candidates = false;
+  c->target_layout = -1;
+  return SVNICP_OK;
+}
+
 int svnicp_set_shard(svnicp_ctx* c, int p_lo, int p_hi) {
   CTX_CHECK(c);
   if (!c->particles_set || p_lo < 0 || p_hi > c->P || p_lo > p_hi)
@@ -339,12 +376,11 @@ int svnicp_set_shard(svnicp_ctx* c, int p_lo, int p_hi) {
 
 // (re)build the target SoA copies in the order the chosen stage-A kernel wants
 static int ensure_target_layout(svnicp_ctx* c) {
-  const char* force = getenv("SVNICP_KNN");  // A/B switch for tests and profiling: v1 | v2 | v3
   int want = 0;
   if (knn_tiles_applicable(c->Mp, c->K)) want = 2;
   else if (knn_scan_plan(c->Mp, c->K, &c->scan_Ms, &c->scan_rank, &c->scan_S2)) want = 1;
-  if (force && !strcmp(force, "v1")) want = 0;
-  if (force && !strcmp(force, "v2")) want = knn_scan_plan(c->Mp, c->K, &c->scan_Ms, &c->scan_rank, &c->scan_S2) ? 1 : 0;
+  if (c->tune.knn == 0) want = 0;   // option "knn": v1 | v2 (A/B for tests and profiling)
+  if (c->tune.knn == 1) want = knn_scan_plan(c->Mp, c->K, &c->scan_Ms, &c->scan_rank, &c->scan_S2) ? 1 : 0;
   c->knn_variant = want;
   c->use_scan = want == 1;
   const int layout = want == 2 ? 1 : 0;
@@ -394,12 +430,8 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, c->qrec.ensure((size_t)B * 6));  // 48-byte records
     HIPCHK(c, c->pool_d.ensure((size_t)kFallbackGrid * 4 * kFallbackQW * c->S));   // fallback rows only
     HIPCHK(c, c->pool_i.ensure((size_t)kFallbackGrid * 4 * kFallbackQW * c->S));
-    {
-      const char* e = getenv("SVNICP_FALLBACK_SLICED_MAX");  // test switch: 0 forces the plain list-mode fallback
-      c->sliced_max = e ? atoi(e) : kFallbackSlicedMax;
-      if (c->sliced_max < 0) c->sliced_max = 0;
-      if (c->sliced_max > kFallbackSlicedMax) c->sliced_max = kFallbackSlicedMax;
-    }
+    c->sliced_max = c->tune.fallback_sliced_max >= 0 ? c->tune.fallback_sliced_max : kFallbackSlicedMax;  // 0 forces the list-mode fallback
+    if (c->sliced_max > kFallbackSlicedMax) c->sliced_max = kFallbackSlicedMax;
     if (c->sliced_max > 0) {
       HIPCHK(c, c->sl_d.ensure((size_t)c->sliced_max * knn_slice_count(c->K) * c->K));
       HIPCHK(c, c->sl_i.ensure((size_t)c->sliced_max * knn_slice_count(c->K) * c->K));
@@ -410,14 +442,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
   }
   HIPCHK(c, c->cand_idx.ensure((size_t)B * c->K));
   HIPCHK(c, c->cand_d2.ensure((size_t)B * c->K));
-  {
-    const char* v1 = getenv("SVNICP_ACCUM_V1");  // A/B switches for tests and profiling
-    const char* am = getenv("SVNICP_ACCUM");     // f64 | valu | mfma | split
-    c->accum_mode = 3;
-    if (am && !strcmp(am, "mfma")) c->accum_mode = 2;
-    if (am && !strcmp(am, "valu")) c->accum_mode = 1;
-    if ((am && !strcmp(am, "f64")) || (v1 && v1[0] == '1')) c->accum_mode = 0;
-  }
+  c->accum_mode = c->tune.accum;   // option "accum": f64 | valu | mfma | split
   HIPCHK(c, c->cmaxb.ensure((size_t)B));
   HIPCHK(c, c->ambig.ensure(1));
   HIPCHK(c, hipMemsetAsync(c->ambig.p, 0, sizeof(int), c->stream));
@@ -425,11 +450,14 @@ int svnicp_align_begin(svnicp_ctx* c) {
   c->hist_I = I; c->hist_P = P;
   const int nshard = c->p_hi - c->p_lo;
   if (nshard > 0) {
-    c->plan = plan_accumulate(nshard, B, c->K, c->num_cus, c->accum_mode);
-    if (getenv("SVNICP_DEBUG"))
+    c->plan = plan_accumulate(nshard, B, c->K, c->num_cus, c->accum_mode, c->tune);
+    if (c->tune.debug)
       fprintf(stderr, "[svnicp] stage-B plan: mode=%d PW=%d WP=%d TP=%d grid=%dx%d tiles/block=%d smem=%zu sgrid=%d pts/block=%d/%d\n", c->plan.f32,
               c->plan.PW, c->plan.WP, c->plan.TP, c->plan.grid_x, c->plan.grid_y, c->plan.tiles_per_block, c->plan.smem,
               c->plan.sgrid_x, c->plan.spts_per_block, c->plan.pts_per_block);
+    if (c->plan.smem > 160u * 1024)   // K > 128 runs the LDS-tile VALU search: its smallest tile must fit one CU's LDS
+      return fail(c, SVNICP_ERR_INVALID, "svnicp_align: knn_count " + std::to_string(c->K) + " needs " + std::to_string(c->plan.smem) +
+                  " bytes of LDS per workgroup (limit 163840): the candidate count is too large for this particle count");
     HIPCHK(c, c->partial.ensure((size_t)c->plan.grid_x * c->plan.Ppad * kNSums));
   } else {
     c->plan = AccumPlan{};
@@ -509,12 +537,12 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
       a.qthr = c->fail_tau.p;
       if (c->prm.record_trace) { HIPCHK(c, c->stat_n.ensure((size_t)c->B)); k.stat_n = c->stat_n.p; }
       HIPCHK(c, hipMemsetAsync(c->fail_count.p, 0, sizeof(int), c->stream));
-      static unsigned long long* dbg_phase = nullptr;  // SVNICP_DEBUG: per-phase wave cycles of k_knn_tiles
+      unsigned long long*& dbg_phase = c->dbg_phase;
       const size_t dbg_waves = (size_t)((n + 255) / 256) * 4;
-      if (getenv("SVNICP_DEBUG")) {
+      if (c->tune.debug && dbg_waves <= 65536) {   // larger launches are simply not instrumented
         if (!dbg_phase) HIPCHK(c, hipMalloc(&dbg_phase, (8 + 8 * 65536) * sizeof(unsigned long long)));
         HIPCHK(c, hipMemsetAsync(dbg_phase, 0, (8 + 8 * dbg_waves) * sizeof(unsigned long long), c->stream));
-        if (dbg_waves <= 65536) k.phase_cycles = dbg_phase;
+        k.phase_cycles = dbg_phase;
       }
       HIPCHK(c, launch_knn_tiles(k, c->stream));
       if (k.phase_cycles) {
@@ -620,8 +648,8 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
   u.eul = c->eul.p; u.opt = c->opt.p; u.optimizer = c->prm.optimizer; u.n_src = (double)c->B;
   HIPCHK(c, prof_begin(c, KC_UPDATE));
   u.uctl = c->uctl.p;
-  static unsigned long long* dbg_upd = nullptr;  // SVNICP_DEBUG: phase cycles of k_particle_update, printed at finish
-  if (getenv("SVNICP_DEBUG")) {
+  unsigned long long*& dbg_upd = c->dbg_upd;     // debug option: phase cycles of k_particle_update, printed at finish
+  if (c->tune.debug) {
     if (!dbg_upd) { HIPCHK(c, hipMalloc(&dbg_upd, 8 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(dbg_upd, 0, 8 * sizeof(unsigned long long))); }
     u.dbg = dbg_upd;
     if (it == c->prm.iterations - 1) {
@@ -632,8 +660,8 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
     }
   }
   if (c->prm.mode == SVNICP_MODE_SVGD) HIPCHK(c, launch_update_svgd(u, c->stream));
-  else if (c->P > fused_update_max_p()) HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream));
-  else if (c->P >= 2 && !getenv("SVNICP_UPDATE_FUSED")) HIPCHK(c, launch_update_front(u, c->stream));  // A/B switch: fused one-kernel step
+  else if (c->P > c->tune.fused_update_max_p) HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream));
+  else if (c->P >= 2 && !c->tune.update_fused) HIPCHK(c, launch_update_front(u, c->stream));  // option "update": fused one-kernel step
   else HIPCHK(c, launch_update(u, c->stream));
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;
@@ -685,6 +713,11 @@ int svnicp_align(svnicp_ctx* c) {
   int rc = svnicp_align_async(c);
   if (rc) return rc;  // negative status, or SVNICP_NO_OPTIMIZER
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prm.mode == SVNICP_MODE_SVGD && c->prm.check_early_stop) {  // finish_iter_ = epoch + 1 (SVGDICP.cpp:128)
+    int v[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(v, c->ctl.p, sizeof v, hipMemcpyDeviceToHost));
+    if (v[0]) c->finish_iter = v[1];
+  }
   return SVNICP_ALIGN_SUCCESS;
 }
 
@@ -733,10 +766,19 @@ int svnicp_get_runtime(svnicp_ctx* c, double out3[3]) {
   double ms[3];
   int rc = svnicp_get_gpu_ms(c, ms);
   if (rc) return rc;
+  // finish_iter_: SVNICP::stein_align never touches it (SVNICP.cpp:95-101 only breaks), SVGDICP::stein_align sets it on
+  // an early stop and nothing resets it (SVGDICP.cpp:42,128)
+  out3[0] = ms[0] * 1e-3; out3[1] = ms[1] * 1e-3; out3[2] = (double)c->finish_iter;
+  return SVNICP_OK;
+}
+
+int svnicp_get_iterations_run(svnicp_ctx* c, int* out) {
+  NEED_RESULT(c);
+  if (!out) return SVNICP_ERR_INVALID;
   int v[2];
-  rc = fetch(c, v, c->ctl.p, sizeof v);
+  const int rc = fetch(c, v, c->ctl.p, sizeof v);
   if (rc) return rc;
-  out3[0] = ms[0] * 1e-3; out3[1] = ms[1] * 1e-3; out3[2] = (double)v[1];
+  *out = v[1];
   return SVNICP_OK;
 }
 

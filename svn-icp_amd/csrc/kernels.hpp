@@ -130,7 +130,19 @@ struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f3
                    int search_f32; /* split variant: 1 = f32-input MFMA search kernel (A/B), 0 = bf16x3 matrix pipe (default) */ };
 // f32: 0 = float64 baseline, 1 = float32 VALU search, 2 = float32 MFMA search fused with the accumulation,
 // 3 = MFMA search kernel + accumulation kernel (2 and 3 fall back to 1 when K > 128 or P <= 8)
-AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32);
+// test / profiling knobs of a context (svnicp_set_option); the defaults are the product configuration
+struct Tuning {
+  int knn = -1;                  // stage A kernel: -1 automatic, 0 streaming only (v1), 1 seeded scan (v2)
+  int fallback_sliced_max = -1;  // stage A: failed queries redone by target slices up to this many (-1 default)
+  int accum = 3;                 // stage B: 0 f64 baseline, 1 f32 VALU search, 2 fused MFMA search, 3 search + accumulate kernels
+  int search_f32 = 0;            // split stage B: 1 = f32-input MFMA search kernel, 0 = bf16x3 matrix pipe
+  int update_fused = 0;          // Stein update: 1 = one fused kernel for 2 <= P <= fused_update_max_p
+  int fused_update_max_p = 128;  // above this the Stein step runs as workgroup-parallel kernels
+  int wgpcu_search = 0, wgpcu_accum = 0;   // workgroups per CU the stage-B grids are sized for (0 = automatic)
+  int tp = 0;                    // fused stage-B variants: source points per LDS tile (0 = automatic)
+  int debug = 0;                 // print plans and per-phase cycle counters to stderr
+};
+AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune);
 int mfma_occupancy_blocks(int PW, int WP, int K, size_t smem);
 hipError_t launch_accumulate_mfma(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);
 hipError_t launch_search_split(const AccumPlan& plan, AccumArgs a, hipStream_t st);         // split variant, kernel 1

@@ -445,7 +445,7 @@ static int occupancy_blocks(const AccumPlan& pl) {
   }
 }
 
-AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32) {
+AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune) {
   AccumPlan pl{};
   if (f32 >= 2 && (K > 128 || n_particles <= 8)) f32 = 1;  // MFMA tiles: 16 particles wide, 128 candidate rows
   pl.f32 = f32;
@@ -472,13 +472,11 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
     };
     pl.smem = (size_t)(WB - 1) * per_wg * kNSums * sizeof(double);
     int occ_s = 4, occ_a = 3;
-    { const char* e = getenv("SVNICP_SEARCH"); pl.search_f32 = (e && !strcmp(e, "f32")) ? 1 : 0; }  // A/B switch
+    pl.search_f32 = tune.search_f32 ? 1 : 0;
     split_occupancy_blocks(PW, WP, K, pl.smem, pl.search_f32 != 0, &occ_s, &occ_a);
-    if (const char* e = getenv("SVNICP_WGPCU")) {  // profiling knob: "<search>,<accumulate>" workgroups per CU
-      int x = 0, y = 0;
-      if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 1 && x <= 16 && y >= 1 && y <= 16) { occ_s = x; occ_a = y; }
-    }
-    else {  // measured at C3: the barrier-free search kernel balances best with two rounds of smaller workgroups;
+    if (tune.wgpcu_search >= 1 && tune.wgpcu_search <= 16 && tune.wgpcu_accum >= 1 && tune.wgpcu_accum <= 16) {
+      occ_s = tune.wgpcu_search; occ_a = tune.wgpcu_accum;   // profiling knob
+    } else {  // measured at C3: the barrier-free search kernel balances best with two rounds of smaller workgroups;
       occ_s *= 2;                        // the accumulate kernel pays per workgroup in k_reduce_partials: 4 per CU
       if (occ_a > 4) occ_a = 4;
     }
@@ -493,10 +491,7 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
   int TP = pass;
   while (TP < 16) TP += pass;                // at least 16 points per tile …
   while (TP > pass && (size_t)TP * per_pt > (f32 == 2 ? 36u : f32 ? 32u : 60u) * 1024) TP -= pass;  // … within a modest LDS footprint
-  if (const char* e = getenv("SVNICP_TP")) {  // profiling knob: source points per LDS tile (rounded to whole passes)
-    const int t = atoi(e);
-    if (t >= pass && (size_t)t * per_pt <= 140u * 1024) TP = t / pass * pass;
-  }
+  if (tune.tp >= pass && (size_t)tune.tp * per_pt <= 140u * 1024) TP = tune.tp / pass * pass;  // profiling knob
   pl.TP = TP;
   const size_t tile_bytes = (size_t)TP * per_pt + 4 * 16 + 16 + (f32 == 2 ? 4 * 64 * 20 + 16 : 0);  // + per-wave operand scratch
   const size_t red_bytes = (size_t)(WB - 1) * per_wg * kNSums * sizeof(double);
@@ -504,10 +499,7 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
   pl.n_tiles = (B + TP - 1) / TP;
   // one resident round of workgroups: a second, partial round would leave most of the chip idle
   int wg_per_cu = occupancy_blocks(pl);
-  if (const char* e = getenv("SVNICP_WGPCU")) {  // profiling knob: workgroups per CU the grid is sized for
-    const int t = atoi(e);
-    if (t >= 1 && t <= 8) wg_per_cu = t;
-  }
+  if (tune.wgpcu_accum >= 1 && tune.wgpcu_accum <= 8) wg_per_cu = tune.wgpcu_accum;  // profiling knob
   int64_t want = (int64_t)num_cus * wg_per_cu / (pl.grid_y > 0 ? pl.grid_y : 1);
   if (want < 1) want = 1;
   int64_t gx = pl.n_tiles < want ? pl.n_tiles : want;

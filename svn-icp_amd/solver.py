@@ -186,6 +186,10 @@ class _SolverBase:
         self._K = int(k)
         self._check(self._L.svnicp_set_k(self._h, int(k)), "svnicp_set_k")
 
+    def set_option(self, name: str, value) -> None:
+        """Test / profiling knob of this context (include/svnicp_hip.h: svnicp_set_option)."""
+        self._check(self._L.svnicp_set_option(self._h, str(name).encode(), str(value).encode()), "svnicp_set_option")
+
     def set_threshold(self, max_dist: float):
         self._check(self._L.svnicp_set_max_dist(self._h, float(max_dist)), "svnicp_set_max_dist")
 
@@ -226,7 +230,8 @@ class _SolverBase:
         return out
 
     def get_runtime(self) -> np.ndarray:
-        """{knn_duration_, update_duration_, finish_iter_} (include/core/SVGDICP.h:94-96), seconds on the GPU."""
+        """{knn_duration_, update_duration_, finish_iter_} (include/core/SVGDICP.h:94-96), seconds on the GPU.
+        finish_iter_ is the reference's: the constructor's ``iterations`` unless an SVGD-mode early stop changed it."""
         return self._getd("runtime", 3)
 
     # -- test / bench taps ------------------------------------------------------------------
@@ -279,6 +284,12 @@ class _SolverBase:
         self._check(self._L.svnicp_get_knn_survivors(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))),
                     "svnicp_get_knn_survivors")
         return out
+
+    def get_iterations_run(self) -> int:
+        """Iterations the last align executed (the early stop may end it before ``iterations``)."""
+        v = C.c_int(0)
+        self._check(self._L.svnicp_get_iterations_run(self._h, C.byref(v)), "svnicp_get_iterations_run")
+        return int(v.value)
 
     def get_ambiguous_steps(self) -> int:
         """Wave steps whose float32 nearest-of-K search had to be redone in float64 (-1: f64 kernel only)."""

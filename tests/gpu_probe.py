@@ -17,7 +17,7 @@ def run(P, B, M, K, I, full, es=False, thr=1e-5, md=1.0, lr=1.0, seed=1, trace=T
     ci = np.array_equal(o.candidates(), s.get_candidates().astype(np.int64))
     cd = np.array_equal(o.candidate_dist2(), s.get_candidate_dist2())
     tr = s.get_trace()
-    n = o.finish_iter()
+    n = o.iterations_run()
     mism = int((tr['corr'][:n] != tro['corr'][:n]).sum())
     dH = np.abs(tr['H'][:n] - tro['H'][:n]).max() / np.abs(tro['H'][:n]).max()
     db = np.abs(tr['b'][:n] - tro['b'][:n]).max() / max(np.abs(tro['b'][:n]).max(), 1e-300)

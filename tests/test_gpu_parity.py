@@ -20,11 +20,12 @@ def _hip_solver(pkg, init, trace=True, **cfg):
 
 
 def _compare(s, o, tro, P, strict_pose=TIGHT):
-    n = o.finish_iter() if o.prm.check_early_stop else o.I
+    n = o.iterations_run()
     assert np.array_equal(s.get_candidates().astype(np.int64), o.candidates()), "stage-A indices"
     assert np.array_equal(s.get_candidate_dist2(), o.candidate_dist2()), "stage-A dist2 bits"
     tr = s.get_trace()
-    assert int(s.get_runtime()[2]) == o.finish_iter()
+    assert s.get_iterations_run() == n
+    assert int(s.get_runtime()[2]) == o.finish_iter()          # finish_iter_: SVN mode never updates it (SVNICP.cpp:95-101)
     assert np.array_equal(tr["corr"][:n], tro["corr"][:n]), "per-iteration correspondence positions"
     assert np.allclose(tr["H"][:n], tro["H"][:n], rtol=1e-11, atol=1e-9)
     assert np.allclose(tr["b"][:n], tro["b"][:n], rtol=1e-9, atol=1e-9)
@@ -97,7 +98,7 @@ def test_hip_svgd_reproduces_golden_and_oracle(hip, orc, name):
     assert np.array_equal(s.get_particle_weight(), g["weights"])
     assert np.allclose(s.get_particle_history(), g["history"], atol=1e-6)
     o = oracle_from_golden(orc, g); o.stein_align()
-    assert int(s.get_runtime()[2]) == o.finish_iter()
+    assert int(s.get_runtime()[2]) == o.finish_iter() and s.get_iterations_run() == o.iterations_run()
     assert np.allclose(s.get_particles(), o.get_particles(), rtol=0, atol=TIGHT)
 
 
@@ -167,10 +168,9 @@ def test_hip_vs_oracle(hip, orc, P, B, M, K, I, full, es, thr, md, lr):
 @pytest.mark.parametrize("B,M,K", [(700, 20000, 7), (300, 9000, 1), (1000, 16384, 128), (513, 8192, 100), (64, 40000, 33),
                                    (900, 12000, 150)])
 def test_stage_a_variants_bit_exact(hip, orc, B, M, K):
-    """The three stage-A kernels — streaming (knn_topk.hip, SVNICP_KNN=v1), seeded f32 pre-filter
+    """The three stage-A kernels — streaming (knn_topk.hip, option knn=v1), seeded f32 pre-filter
     (knn_scan.hip, v2) and Morton-tile pruning (knn_tiles.hip, default for K <= 128) — must all give
     indices and dist² bit-identical to the oracle's f64 brute force."""
-    import os
     src, tgt = hip.scans.random_clouds(B, M, seed=B + K, extent=40.0)
     src = src + np.array([100.0, -50.0, 3.0])      # large coordinates: the filter slack must cover them
     tgt = tgt + np.array([100.0, -50.0, 3.0])
@@ -179,14 +179,11 @@ def test_stage_a_variants_bit_exact(hip, orc, B, M, K):
     oi, od = orc.knn_topk(src, tgt, K)
     fbs = {}
     for variant in ("v1", "v2", "default"):
+        s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init)
         if variant != "default":
-            os.environ["SVNICP_KNN"] = variant
-        try:
-            s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init)
-            s.set_initial_mean((hip.scans.rot_zyx(0.01, -0.02, 0.03), np.array([0.3, -0.2, 0.1])))
-            s.stein_align()
-        finally:
-            os.environ.pop("SVNICP_KNN", None)
+            s.set_option("knn", variant)
+        s.set_initial_mean((hip.scans.rot_zyx(0.01, -0.02, 0.03), np.array([0.3, -0.2, 0.1])))
+        s.stein_align()
         fbs[variant] = s.get_knn_fallbacks()
         q = orc.transform(src, hip.scans.rot_zyx(0.01, -0.02, 0.03), np.array([0.3, -0.2, 0.1]))
         oi, od = orc.knn_topk(q, tgt, K)
@@ -205,9 +202,8 @@ def test_stage_a_fallback_on_pool_overflow(hip, orc, sliced_max, K):
     """Clustered duplicates: thousands of targets at exactly the same distance overflow the
     candidate pool of every query; all of them must be redone by the streaming fallback and still
     come out bit-exact (ties broken by lowest index).  Both fallback regimes: target-sliced scan +
-    merge (few failures, default here) and one wave per two queries (SVNICP_FALLBACK_SLICED_MAX
+    merge (few failures, default here) and one wave per two queries (option fallback_sliced_max
     below the failure count)."""
-    import os
     rng = np.random.default_rng(3)
     centers = rng.normal(size=(6, 3)) * 5
     tgt = np.repeat(centers, 2000, axis=0).astype(np.float32).astype(np.float64)   # M = 12000, 2000 duplicates each
@@ -215,12 +211,10 @@ def test_stage_a_fallback_on_pool_overflow(hip, orc, sliced_max, K):
     src = (centers[rng.integers(0, 6, 300)] + rng.normal(size=(300, 3)) * 0.1)
     init = np.zeros((6, 1))
     cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
+    s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init)
     if sliced_max is not None:
-        os.environ["SVNICP_FALLBACK_SLICED_MAX"] = sliced_max
-    try:
-        s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
-    finally:
-        os.environ.pop("SVNICP_FALLBACK_SLICED_MAX", None)
+        s.set_option("fallback_sliced_max", sliced_max)
+    s.stein_align()
     assert s.get_knn_fallbacks() == 300
     oi, od = orc.knn_topk(src, tgt, K)
     assert np.array_equal(s.get_candidates().astype(np.int64), oi)
@@ -230,27 +224,27 @@ def test_stage_a_fallback_on_pool_overflow(hip, orc, sliced_max, K):
 @pytest.mark.parametrize("P,full,K", [(70, False, 60), (20, True, 60), (128, False, 100), (9, False, 128), (40, False, 17),
                                       (33, False, 1), (65, False, 80), (17, False, 97), (30, False, 112)])
 def test_stage_b_f32_search_is_bit_identical_to_f64_kernel(hip, P, full, K):
-    """stein_iter.hip / stein_mfma.hip: the float32 searches (VALU: SVNICP_ACCUM=valu, matrix cores: default)
-    must reproduce the float64 baseline kernel (SVNICP_ACCUM=f64) bit for bit — same correspondences,
-    same sums, same particles."""
-    import os
+    """stein_iter.hip / stein_mfma.hip / stein_split.hip: the float32 searches (VALU: option accum=valu, fused f32 matrix
+    cores: accum=mfma, bf16x3 matrix pipe + separate accumulation: accum=split, the default; its f32-input sibling:
+    search=f32) must reproduce the float64 baseline kernel (accum=f64) — same correspondences, same sums."""
     src, tgt = hip.scans.random_clouds(6000, 20000, seed=77, extent=30.0)
     src = src + np.array([80.0, -40.0, 2.0]); tgt = tgt + np.array([80.0, -40.0, 2.0])
     init = hip.scans.make_particles(P, seed=P) * 0.5
     cfg = dict(iterations=6, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=full)
     out = {}
-    for mode in ("f64", "valu", "mfma", "split"):
-        os.environ["SVNICP_ACCUM"] = mode
-        try:
-            s = _hip_solver(hip, init, trace=True, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
-        finally:
-            os.environ.pop("SVNICP_ACCUM", None)
+    for mode in ("f64", "valu", "mfma", "split", "split_f32"):
+        s = _hip_solver(hip, init, trace=True, **cfg); s.add_cloud(src, tgt, init)
+        s.set_option("accum", mode.split("_")[0])
+        if mode == "split_f32":
+            s.set_option("search", "f32")
+        s.stein_align()
         out[mode] = (s.get_particles(), s.get_trace()["corr"], s.get_trace()["H"], s.get_ambiguous_steps())
     assert out["f64"][3] == -1 and out["valu"][3] >= 0 and out["mfma"][3] >= 0 and out["split"][3] >= 0
     n_steps = 6 * ((P + 63) // 64) * 6000
     assert out["mfma"][3] < 0.5 * n_steps or K == 1, "the MFMA search should decide most wave steps itself"
-    for mode in ("valu", "mfma", "split"):
+    for mode in ("valu", "mfma", "split", "split_f32"):
         assert np.array_equal(out["f64"][1], out[mode][1]), mode   # correspondences: always identical
+    assert np.array_equal(out["split"][2], out["split_f32"][2])    # same winners, same accumulation kernel: same bits
     for mode in ("valu", "mfma"):                                  # same tiling as the f64 kernel: same summation order
         assert np.array_equal(out["f64"][2], out[mode][2]), mode
         assert np.array_equal(out["f64"][0], out[mode][0]), mode
@@ -302,6 +296,23 @@ def test_context_reuse_with_changing_sizes(hip, orc):
         o = orc.Solver(init, **dict(cfg, knn_count=K, max_dist=md)); o.add_cloud(src, tgt, init); o.stein_align()
         assert np.array_equal(s.get_candidates().astype(np.int64), o.candidates())
         assert np.abs(s.get_transformation() - o.get_transformation()).max() < TIGHT
+
+
+def test_knn_count_beyond_the_lds_budget_is_refused(hip, orc):
+    """K <= 128 runs on the matrix pipe; larger K on the LDS-tile VALU search, whose smallest tile has to fit the 160 KB of
+    LDS: K = 256 still runs (and matches the oracle), K = 1000 is refused in stein_align with a clear message instead of
+    failing at a kernel launch after stage A has already run."""
+    src, tgt = hip.scans.random_clouds(600, 3000, seed=2)
+    init = hip.scans.make_particles(6, seed=2) * 0.3
+    cfg = dict(iterations=2, lr=1.0, max_dist=1.0, knn_count=256, svn_full_grad=False)
+    o = orc.Solver(init, **cfg); o.add_cloud(src, tgt, init); o.stein_align()
+    s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+    assert np.array_equal(s.get_candidates().astype(np.int64), o.candidates())
+    assert np.abs(s.get_transformation() - o.get_transformation()).max() < TIGHT
+    s.set_k(1000)
+    s.add_cloud(src, tgt, init)
+    with pytest.raises(hip.SvnIcpError, match="LDS"):
+        s.stein_align()
 
 
 def test_error_paths(hip):

@@ -114,7 +114,7 @@ def test_oracle_reproduces_golden(orc, name):
     assert np.allclose(s.get_particle_history(), g["history"], atol=1e-6)
     # rows after an early stop stay zero (break before the history write, SVNICP.cpp:95-107)
     if n < g["cfg"]["iterations"] or g["cfg"]["check_early_stop"]:
-        run = s.finish_iter()
+        run = s.iterations_run()
         assert np.all(s.get_particle_history()[run - 1 if g["cfg"]["check_early_stop"] and run <= n else run:] == 0)
 
 

@@ -39,7 +39,7 @@ def _worker(rank, world, port, case, out_dir):
     s.stein_align()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=s.get_particles(), cov=s.get_cov_matrix(),
              mean=s.get_transformation(), hist=s.get_particle_history(), cand=s.be.solver.candidates(),
-             fin=s.be.solver.finish_iter(), shard=np.array(shard_range(P, world, rank)))
+             fin=s.be.solver.iterations_run(), shard=np.array(shard_range(P, world, rank)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,9 +70,9 @@ def test_two_ranks_gloo_equal_unsharded(case, tmp_path, pkg, orc):
         assert np.array_equal(r["particles"], o.get_particles())       # bit-identical to the unsharded run
         assert np.array_equal(r["cov"], o.get_cov_matrix())
         assert np.array_equal(r["hist"], o.get_particle_history())
-        assert int(r["fin"]) == o.finish_iter()
+        assert int(r["fin"]) == o.iterations_run()
     if es:
-        assert o.finish_iter() < I
+        assert o.iterations_run() < I
 
 
 def test_shard_range_covers_everything(pkg):

@@ -264,19 +264,6 @@ __device__ __forceinline__ float pack_slot3(float v, unsigned int bits) {  // (v
 __device__ __forceinline__ float fmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fmed3_raw(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// the value of this lane and of the lane 32 (16) away, in no particular order, without the LDS crossbar:
-// v_permlane32_swap / v_permlane16_swap (gfx950) on two copies leave {own, other} in (lo, hi) for every lane
-__device__ __forceinline__ void pair32(float v, float& lo, float& hi) {
-  const unsigned int x = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-  lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void pair16(float v, float& lo, float& hi) {
-  const unsigned int x = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-  lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
-}
-
 constexpr int kQueueCap = 1024;  // undecided pairs a workgroup can defer to its exact pass (4 KB of LDS)
 
 // exact float64 nearest-of-K of one (source point, particle) pair, candidate-parallel over G lanes (lane id `sub` in
@@ -328,22 +315,22 @@ __device__ __forceinline__ int exact_nearest_of_k(const AccumArgs& a, const doub
 
 constexpr float kEpsBf16 = 64.0f * 5.9604644775390625e-08f;
 
-// ABL: development ablations (built only with -DSVNICP_DEV_ABLATE, results meaningless): 1 no tracking, 2 no MFMA,
-// 3 no transform phase, 4 no tail / exact path, 5 no operand splits, 6 no lane-group merge
-template <int PW, int WP, int NRB, bool TAIL, int ABL = 0>
+// Work split: all four waves of a workgroup walk source points (one point per wave step when PW = 64); a wave handles
+// ALL WP groups of PW particles of its points one after the other, so a point's table rows are fetched and split into
+// bf16 pieces once for the whole workgroup's particles.
+template <int PW, int WP, int NRB, bool TAIL>
 #ifndef SVNICP_SEARCH_WAVES
-#define SVNICP_SEARCH_WAVES 6
+#define SVNICP_SEARCH_WAVES 4
 #endif
 __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(AccumArgs a) {
   if (a.ctl[0]) return;
   constexpr int BW = kWave / PW;   // source points per wave step (1, 2, 4)
-  constexpr int WB = 4 / WP;       // waves along the source-point axis
   constexpr int CBP = PW / 16;     // 16-particle column blocks per source point (4, 2, 1)
   constexpr int NPT = 4 / CBP;     // distinct source points per wave step
-  constexpr int ST = WB * BW;      // source points between two steps of a wave
+  constexpr int ST = 4 * BW;       // source points between two steps of a wave (four waves along the points)
   constexpr bool PIPE = NPT == 1;  // one point per step: its table rows are fetched a step ahead
-  __shared__ float4 s_scr4[4][64];       // per wave: (−2x', 1) of each particle lane
-  __shared__ double s_pose[WP][12][64];  // the lane's total pose, re-read every step: 24 VGPRs less than keeping it
+  __shared__ float4 s_scr4[4][64];       // per wave: (−2x', 1) of each particle lane of the group in flight
+  __shared__ double s_pose[WP][12][64];  // the lanes' total poses, re-read every step: 24 VGPRs less than keeping them
   __shared__ unsigned int s_queue[kQueueCap];   // undecided pairs: (point − blk_lo) << 8 | particle lane of the workgroup
   __shared__ unsigned int s_qn, s_qsteps;
   const int tid = threadIdx.x;
@@ -352,19 +339,16 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
   for (int i = 0; i < kQueueCap / NT; ++i) s_queue[tid + i * NT] = 0xffffffffu;   // a step that straddles the end leaves holes
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wave % WP, wb = wave / WP;
   const int pl = lane % PW, bs = lane / PW;
   const int mj = lane & 15, mk = lane >> 4;
-  const int pidx = blockIdx.y * (WP * PW) + wp * PW + pl;
-  const int p = a.p_lo + pidx;
-  const bool pvalid = p < a.p_hi;
-  const double* rp = a.Rtot + 12 * (size_t)(pvalid ? p : a.p_lo);
+  const int pbase = blockIdx.y * (WP * PW);   // first particle lane of this workgroup
+  for (int g = wave; g < WP; g += 4) {        // wave g fills group g's poses (WP <= 4)
+    const int p = a.p_lo + pbase + g * PW + pl;
+    const double* rp = a.Rtot + 12 * (size_t)(p < a.p_hi ? p : a.p_lo);
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s_pose[wp][i][lane] = rp[i];   // waves that share wp write identical values
+    for (int i = 0; i < 12; ++i) s_pose[g][i][lane] = rp[i];
+  }
   const int K = a.K;
-  float4* scr4 = s_scr4[wave];
-  const float* scr4f = reinterpret_cast<const float*>(scr4);
-  const double (*pose)[64] = s_pose[wp];
   const SVNICP_CONST_AS double* csrc = (const SVNICP_CONST_AS double*)a.src;
   const SVNICP_CONST_AS double* canc = (const SVNICP_CONST_AS double*)a.anchor;
   const SVNICP_CONST_AS float* ccmax = (const SVNICP_CONST_AS float*)a.cmax;
@@ -373,7 +357,7 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
   const int64_t blk_lo = (int64_t)blockIdx.x * a.spts_per_block;
   const int64_t blk_hi = (blk_lo + a.spts_per_block < a.B) ? blk_lo + a.spts_per_block : a.B;
   __syncthreads();
-  const int64_t nfirst = blk_lo + wb * BW;
+  const int64_t nfirst = blk_lo + wave * BW;
 
   v4f alo_n, ahi_n;   // PIPE: table rows of the NEXT step, in flight while this step's tiles run
   if constexpr (PIPE) {
@@ -386,162 +370,158 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
   for (int64_t n = nfirst; n < blk_hi; n += ST) {  // wave-uniform
     const int64_t b = n + bs;
     const bool inb = b < blk_hi;
-    const bool valid = pvalid && inb;
     const int64_t bl = inb ? b : n;
-    float E;
-    if constexpr (ABL == 3) {
-      E = 1e-6f;
-      scr4[lane] = make_float4(0.01f * lane, -0.02f * lane, 0.1f, 1.0f);
-    } else {
-      const SVNICP_CONST_AS double* sp = csrc + 3 * bl;
-      const SVNICP_CONST_AS double* an = canc + 3 * bl;               // first candidate = origin of the local frame
-      const double s0 = sp[0], s1 = sp[1], s2 = sp[2];
-      const double T0 = (s0 * pose[0][lane] + s1 * pose[1][lane] + s2 * pose[2][lane]) + pose[9][lane];   // SVNICP.cpp:62-64
-      const double T1 = (s0 * pose[3][lane] + s1 * pose[4][lane] + s2 * pose[5][lane]) + pose[10][lane];
-      const double T2 = (s0 * pose[6][lane] + s1 * pose[7][lane] + s2 * pose[8][lane]) + pose[11][lane];
-      const float xf0 = (float)(T0 - an[0]), xf1 = (float)(T1 - an[1]), xf2 = (float)(T2 - an[2]);
-      const float X = __builtin_fmaxf(__builtin_fabsf(xf0), __builtin_fmaxf(__builtin_fabsf(xf1), __builtin_fabsf(xf2)));
-      const float C = ccmax[bl];
-      E = kEpsBf16 * (C + X) * (C + X);
-      scr4[lane] = make_float4(-2.0f * xf0, -2.0f * xf1, -2.0f * xf2, 1.0f);
-    }
-    __builtin_amdgcn_wave_barrier();
+    const SVNICP_CONST_AS double* sp = csrc + 3 * bl;
+    const SVNICP_CONST_AS double* an = canc + 3 * bl;               // first candidate = origin of the local frame
+    const double s0 = sp[0], s1 = sp[1], s2 = sp[2];
+    const double a0 = an[0], a1 = an[1], a2 = an[2];
+    const float C = ccmax[bl];
 
-    float b1[4], b2[4];
-#pragma unroll
-    for (int q = 0; q < NPT; ++q) {
-      v4f alo, ahi;
-      if constexpr (PIPE) {
-        alo = alo_n; ahi = ahi_n;
-        int64_t nn = n + ST;
-        nn = nn < blk_hi ? nn : n;
-        const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)nn * 128 + lane;
-        alo_n = rowp[0];
-        if constexpr (NRB > 4) ahi_n = rowp[64];
-      } else {
-        int64_t bq = n + q;
-        bq = bq < blk_hi ? bq : n;
-        const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)bq * 128 + lane;
-        alo = rowp[0];
-        ahi = alo;
-        if constexpr (NRB > 4) ahi = rowp[64];
-      }
-      bf8 afr[NRB];
+    // the A operands of a point: its table rows split into bf16 pieces.  One point per step (PW = 64): split once here and
+    // used by every particle group; several points per step (PW < 64, one particle group): split when the column blocks reach
+    // the point
+    bf8 afr[NRB];
+    auto split_rows = [&](v4f alo, v4f ahi) {
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) {
         const float v = rb == 0 ? alo.x : rb == 1 ? alo.y : rb == 2 ? alo.z : rb == 3 ? alo.w
                       : rb == 4 ? ahi.x : rb == 5 ? ahi.y : rb == 6 ? ahi.z : ahi.w;
-        if constexpr (ABL == 5) { u4v t; t[0] = __float_as_uint(v); t[1] = t[0]; t[2] = t[0]; t[3] = t[0]; afr[rb] = __builtin_bit_cast(bf8, t); }
-        else afr[rb] = split_a3(v);
+        afr[rb] = split_a3(v);
       }
-      float braw[CBP];
+    };
+    if constexpr (PIPE) {
+      const v4f alo = alo_n, ahi = ahi_n;
+      int64_t nn = n + ST;
+      nn = nn < blk_hi ? nn : n;
+      const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)nn * 128 + lane;
+      alo_n = rowp[0];
+      if constexpr (NRB > 4) ahi_n = rowp[64];
+      split_rows(alo, ahi);
+    }
+
+#pragma nounroll
+    for (int g = 0; g < WP; ++g) {   // not unrolled: the groups would only compete for registers
+      float E;
+      {
+        const double (*pose)[64] = s_pose[g];
+        const double T0 = (s0 * pose[0][lane] + s1 * pose[1][lane] + s2 * pose[2][lane]) + pose[9][lane];   // SVNICP.cpp:62-64
+        const double T1 = (s0 * pose[3][lane] + s1 * pose[4][lane] + s2 * pose[5][lane]) + pose[10][lane];
+        const double T2 = (s0 * pose[6][lane] + s1 * pose[7][lane] + s2 * pose[8][lane]) + pose[11][lane];
+        const float xf0 = (float)(T0 - a0), xf1 = (float)(T1 - a1), xf2 = (float)(T2 - a2);
+        const float X = __builtin_fmaxf(__builtin_fabsf(xf0), __builtin_fmaxf(__builtin_fabsf(xf1), __builtin_fabsf(xf2)));
+        E = kEpsBf16 * (C + X) * (C + X);
+        if (g > 0) __builtin_amdgcn_wave_barrier();      // the previous group's readers are done with the scratch
+        s_scr4[wave][lane] = make_float4(-2.0f * xf0, -2.0f * xf1, -2.0f * xf2, 1.0f);
+        __builtin_amdgcn_wave_barrier();
+      }
+      const float* scr4f = reinterpret_cast<const float*>(s_scr4[wave]);
+      float b1[4], b2[4];
+      float braw[4];
 #pragma unroll
-      for (int c = 0; c < CBP; ++c) braw[c] = scr4f[(16 * (q * CBP + c) + mj) * 4 + mk];
+      for (int cb = 0; cb < 4; ++cb) braw[cb] = scr4f[(16 * cb + mj) * 4 + mk];
 #pragma unroll
-      for (int c = 0; c < CBP; ++c) {
-        const int cb = q * CBP + c;
-        bf8 bfr;
-        if constexpr (ABL == 5) { u4v t; t[0] = __float_as_uint(braw[c]); t[1] = t[0]; t[2] = t[0]; t[3] = 0u; bfr = __builtin_bit_cast(bf8, t); }
-        else bfr = split_b3(braw[c]);
+      for (int cb = 0; cb < 4; ++cb) {
+        if constexpr (!PIPE) {
+          if (cb % CBP == 0) {
+            int64_t bq = n + cb / CBP;
+            bq = bq < blk_hi ? bq : n;
+            const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)bq * 128 + lane;
+            const v4f alo = rowp[0];
+            v4f ahi = alo;
+            if constexpr (NRB > 4) ahi = rowp[64];
+            split_rows(alo, ahi);
+          }
+        }
+        const bf8 bfr = split_b3(braw[cb]);
         const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
         float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
-        auto tile = [&](int rb) -> v4f {
-          if constexpr (ABL == 2) { const u4v t = __builtin_bit_cast(u4v, afr[rb]); const u4v w = __builtin_bit_cast(u4v, bfr);
-            const v4f r = {__uint_as_float(t[0] ^ w[0]), __uint_as_float(t[1] ^ w[1]), __uint_as_float(t[2] ^ w[2]), __uint_as_float(t[0] ^ w[3])}; return r; }
-          else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[rb], bfr, zero, 0, 0, 0);
-        };
-        v4f dcur = tile(0);
+        v4f dcur = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0], bfr, zero, 0, 0, 0);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {  // tile rb+1 goes to the matrix pipe before the VALU consumes tile rb
           v4f dnext = dcur;
-          if (rb + 1 < NRB) dnext = tile(rb + 1);
-          if constexpr (ABL == 1) { asm volatile("" :: "v"(dcur)); m1 = dcur[0]; m2 = dcur[1]; }
-          else {
+          if (rb + 1 < NRB) dnext = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[rb + 1], bfr, zero, 0, 0, 0);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const float pk = pack_slot3(dcur[v], (unsigned int)(rb * 4 + v));
-              m2 = fmed3_raw(m1, m2, pk);
-              m1 = fmin_raw(m1, pk);
-            }
+          for (int v = 0; v < 4; ++v) {
+            const float pk = pack_slot3(dcur[v], (unsigned int)(rb * 4 + v));
+            m2 = fmed3_raw(m1, m2, pk);
+            m1 = fmin_raw(m1, pk);
           }
           dcur = dnext;
         }
         b1[cb] = m1; b2[cb] = m2;
       }
-    }
-    // the four lanes that share a particle (lane groups mk = 0..3): a 4 x 4 transpose-reduce over the lane groups — after
-    // v_permlane16_swap on the registers of column blocks (0,1) and (2,3) a lane holds, for the column block of its parity,
-    // its own entry and its row partner's; after v_permlane32_swap on those two results lane group mk holds both halves of
-    // column block mk.  Six swaps, no copies, no selects; the result lands in the lane that owns the particle.
+      // the four lanes that share a particle (lane groups mk = 0..3): a 4 x 4 transpose-reduce over the lane groups — after
+      // v_permlane16_swap on the registers of column blocks (0,1) and (2,3) a lane holds, for the column block of its parity,
+      // its own entry and its row partner's; after v_permlane32_swap on those two results lane group mk holds both halves of
+      // column block mk.  Six swaps, no copies, no selects; the result lands in the lane that owns the particle.
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) b1[cb] = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(b1[cb]), 0x60u, (unsigned int)mk << 5, 0xBA));
-    auto merge2 = [&](float p1, float q1, float p2, float q2, float& o1, float& o2) {
-      o1 = fmin_raw(p1, q1);
-      o2 = fmin_raw(fmax_raw(p1, q1), fmin_raw(p2, q2));
-    };
-    float b1own, b2own;
-    if constexpr (ABL == 6) { b1own = b1[0]; b2own = b2[0]; }
-    else {
-      float h1[2], h2[2];
+      for (int cb = 0; cb < 4; ++cb) b1[cb] = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(b1[cb]), 0x60u, (unsigned int)mk << 5, 0xBA));
+      auto merge2 = [&](float p1, float q1, float p2, float q2, float& o1, float& o2) {
+        o1 = fmin_raw(p1, q1);
+        o2 = fmin_raw(fmax_raw(p1, q1), fmin_raw(p2, q2));
+      };
+      float b1own, b2own;
+      {
+        float h1[2], h2[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(b1[2 * j]), __float_as_uint(b1[2 * j + 1]), false, false);
-        const auto r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(b2[2 * j]), __float_as_uint(b2[2 * j + 1]), false, false);
-        merge2(__uint_as_float(r1[0]), __uint_as_float(r1[1]), __uint_as_float(r2[0]), __uint_as_float(r2[1]), h1[j], h2[j]);
+        for (int j = 0; j < 2; ++j) {
+          const auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(b1[2 * j]), __float_as_uint(b1[2 * j + 1]), false, false);
+          const auto r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(b2[2 * j]), __float_as_uint(b2[2 * j + 1]), false, false);
+          merge2(__uint_as_float(r1[0]), __uint_as_float(r1[1]), __uint_as_float(r2[0]), __uint_as_float(r2[1]), h1[j], h2[j]);
+        }
+        const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h1[0]), __float_as_uint(h1[1]), false, false);
+        const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h2[0]), __float_as_uint(h2[1]), false, false);
+        merge2(__uint_as_float(r1[0]), __uint_as_float(r1[1]), __uint_as_float(r2[0]), __uint_as_float(r2[1]), b1own, b2own);
       }
-      const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h1[0]), __float_as_uint(h1[1]), false, false);
-      const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h2[0]), __float_as_uint(h2[1]), false, false);
-      merge2(__uint_as_float(r1[0]), __uint_as_float(r1[1]), __uint_as_float(r2[0]), __uint_as_float(r2[1]), b1own, b2own);
-    }
-    if constexpr (TAIL && ABL != 4 && ABL != 8) {
-      const SVNICP_CONST_AS v4f* tl = ctail + (size_t)bl * 4;
-      const float4 mm = scr4[lane];   // (−2x', 1) of this lane's own particle
+      if constexpr (TAIL) {
+        const SVNICP_CONST_AS v4f* tl = ctail + (size_t)bl * 4;
+        const float4 mm = s_scr4[wave][lane];   // (−2x', 1) of this lane's own particle
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const v4f c = tl[t];  // (c'x, c'y, c'z, |c'|²), a finite sentinel past K
-        const float sc = __builtin_fmaf(c.x, mm.x, __builtin_fmaf(c.y, mm.y, __builtin_fmaf(c.z, mm.z, c.w)));
-        const float pk = pack_slot(sc, 0x7fu, (unsigned int)(NRB * 4 + t));  // slot of candidate 16·NRB + t, lane group 0
-        b2own = fmed3_raw(b1own, b2own, pk);
-        b1own = fmin_raw(b1own, pk);
+        for (int t = 0; t < 4; ++t) {
+          const v4f c = tl[t];  // (c'x, c'y, c'z, |c'|²), a finite sentinel past K
+          const float sc = __builtin_fmaf(c.x, mm.x, __builtin_fmaf(c.y, mm.y, __builtin_fmaf(c.z, mm.z, c.w)));
+          const float pk = pack_slot(sc, 0x7fu, (unsigned int)(NRB * 4 + t));  // slot of candidate 16·NRB + t, lane group 0
+          b2own = fmed3_raw(b1own, b2own, pk);
+          b1own = fmin_raw(b1own, pk);
+        }
       }
+
+      const int pin = g * PW + pl;                        // particle lane inside the workgroup
+      const bool valid = inb && (a.p_lo + pbase + pin) < a.p_hi;
+      const unsigned int wbits = __float_as_uint(b1own);
+      int kb = (int)(((wbits & 0x1cu) << 2) | ((wbits >> 3) & 0xcu) | (wbits & 3u));  // 16·rb + 4·mk + v
+      const float thr = 2.0f * E + 3.0517578125e-05f * (__builtin_fabsf(b1own) + __builtin_fabsf(b2own)) + 1.0e-30f;
+      const bool ambiguous = valid && (!(b2own - b1own > thr) || kb >= K);
+      kb = kb < K ? kb : 0;
+      unsigned long long am = __ballot(ambiguous);
+      if (am) {  // rare (about one wave step in ten, a lane or two each): queue the undecided pairs for the exact pass below
+        const int cnt = __builtin_popcountll(am);
+        int base = 0;
+        if (lane == 0) { base = (int)atomicAdd(&s_qn, (unsigned int)cnt); atomicAdd(&s_qsteps, 1u); }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + cnt <= kQueueCap) {
+          if (ambiguous) {
+            const int rank = __builtin_popcountll(am & ((1ull << lane) - 1ull));
+            s_queue[base + rank] = ((unsigned int)(b - blk_lo) << 8) | (unsigned int)pin;
+          }
+        } else {  // queue full (degenerate clouds: every pair tied): settle this step's pairs here, one lane at a time
+          do {
+            const int L = (int)__builtin_ctzll(am);
+            am &= am - 1;
+            const int ke = exact_nearest_of_k<kWave>(a, s_pose[g], n + L / PW, L % PW, K, lane);
+            if (lane == L) kb = ke;
+          } while (am);
+        }
+      }
+      if (inb) a.kbest[(size_t)b * a.Ppad + (pbase + pin)] = (uint8_t)kb;
     }
     __builtin_amdgcn_wave_barrier();  // scratch is rewritten by the next step
-
-    const unsigned int wbits = __float_as_uint(b1own);
-    int kb = (int)(((wbits & 0x1cu) << 2) | ((wbits >> 3) & 0xcu) | (wbits & 3u));  // 16·rb + 4·mk + v
-    const float thr = 2.0f * E + 3.0517578125e-05f * (__builtin_fabsf(b1own) + __builtin_fabsf(b2own)) + 1.0e-30f;
-    const bool ambiguous = valid && (!(b2own - b1own > thr) || kb >= K);
-    kb = kb < K ? kb : 0;
-    unsigned long long am = __ballot(ambiguous);
-    if constexpr (ABL == 4 || ABL == 9) am = 0;
-    if constexpr (ABL == 11) { if (am == 0x8000000000000001ull) kb = 1; am = 0; }
-    if (am) {  // rare (about one wave step in ten, a lane or two each): queue the undecided pairs for the exact pass below
-      const int cnt = __builtin_popcountll(am);
-      int base = 0;
-      if (lane == 0) { base = (int)atomicAdd(&s_qn, (unsigned int)cnt); atomicAdd(&s_qsteps, 1u); }
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (base + cnt <= kQueueCap) {
-        if (ambiguous) {
-          const int rank = __builtin_popcountll(am & ((1ull << lane) - 1ull));
-          s_queue[base + rank] = ((unsigned int)(b - blk_lo) << 8) | (unsigned int)(wp * PW + pl);
-        }
-      } else {  // queue full (degenerate clouds: every pair tied): settle this step's pairs here, one lane at a time
-        do {
-          const int L = (int)__builtin_ctzll(am);
-          am &= am - 1;
-          const int ke = exact_nearest_of_k<kWave>(a, pose, n + L / PW, L % PW, K, lane);
-          if (lane == L) kb = ke;
-        } while (am);
-      }
-    }
-    if (inb) a.kbest[(size_t)b * a.Ppad + pidx] = (uint8_t)kb;
   }
 
   // exact pass over the queued pairs: 32 lanes per pair, all waves of the workgroup, no lane waits for another pair
   __syncthreads();
   {
-    unsigned int total = s_qn < (unsigned int)kQueueCap ? s_qn : (unsigned int)kQueueCap;
-    if constexpr (ABL == 10) total = 0;
+    const unsigned int total = s_qn < (unsigned int)kQueueCap ? s_qn : (unsigned int)kQueueCap;
     // steps that did not fit (base + cnt > kQueueCap) were settled in the loop and left their slots at the sentinel
     constexpr int kExactLanes = 32;
     const int sub = lane & (kExactLanes - 1);
@@ -551,7 +531,7 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
       const int64_t be = blk_lo + (int64_t)(ent >> 8);
       const int pin = (int)(ent & 0xffu);
       const int ke = exact_nearest_of_k<kExactLanes>(a, s_pose[pin / PW], be, pin % PW, K, sub);
-      if (sub == 0) a.kbest[(size_t)be * a.Ppad + (blockIdx.y * (WP * PW) + pin)] = (uint8_t)ke;
+      if (sub == 0) a.kbest[(size_t)be * a.Ppad + (pbase + pin)] = (uint8_t)ke;
     }
     if (tid == 0 && a.ambig_count && s_qsteps) atomicAdd(a.ambig_count, (int)s_qsteps);
   }
@@ -703,26 +683,6 @@ inline int row_code_for(int K) { return K <= 16 ? 1 : K <= 32 ? 2 : K <= 64 ? 4 
 
 template <int PW, int WP, int NRB, bool TAIL>
 hipError_t launch_s(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
-#ifdef SVNICP_DEV_ABLATE
-  if constexpr (PW == 64 && WP == 2 && NRB == 6 && TAIL) {
-    static const int abl = [] { const char* e = getenv("SVNICP_ABLATE"); return e ? atoi(e) : 0; }();
-    const dim3 g(plan.sgrid_x, plan.grid_y), blk(NT);
-    switch (abl) {
-      case 1: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 1>), g, blk, 0, st, a); return hipGetLastError();
-      case 2: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 2>), g, blk, 0, st, a); return hipGetLastError();
-      case 3: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 3>), g, blk, 0, st, a); return hipGetLastError();
-      case 4: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 4>), g, blk, 0, st, a); return hipGetLastError();
-      case 5: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 5>), g, blk, 0, st, a); return hipGetLastError();
-      case 6: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 6>), g, blk, 0, st, a); return hipGetLastError();
-      case 7: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 7>), g, blk, 0, st, a); return hipGetLastError();
-      case 8: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 8>), g, blk, 0, st, a); return hipGetLastError();
-      case 9: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 9>), g, blk, 0, st, a); return hipGetLastError();
-      case 10: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 10>), g, blk, 0, st, a); return hipGetLastError();
-      case 11: hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL, 11>), g, blk, 0, st, a); return hipGetLastError();
-      default: break;
-    }
-  }
-#endif
   if (plan.search_f32) hipLaunchKernelGGL((k_stein_search_mfma<PW, WP, NRB, TAIL>), dim3(plan.sgrid_x, plan.grid_y), dim3(NT), 0, st, a);
   else hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL>), dim3(plan.sgrid_x, plan.grid_y), dim3(NT), 0, st, a);
   return hipGetLastError();

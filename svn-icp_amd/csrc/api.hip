@@ -659,7 +659,13 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
       fprintf(stderr, "[svnicp] k_particle_update thread-0 cycles (summed over launches so far): prepare %llu median %llu direction %llu pose %llu tail %llu\n", h[0], h[1], h[2], h[3], h[4]);
     }
   }
-  if (c->prm.mode == SVNICP_MODE_SVGD) HIPCHK(c, launch_update_svgd(u, c->stream));
+  u.svgd = 0;
+  if (c->prm.mode == SVNICP_MODE_SVGD) {
+    // one workgroup up to the same particle count as the SVN step; above it the workgroup-parallel chain (its median
+    // select, one wavefront per particle for the Stein direction and the optimizer step)
+    if (c->P > c->tune.fused_update_max_p) { u.svgd = 1; HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream)); }
+    else HIPCHK(c, launch_update_svgd(u, c->stream));
+  }
   else if (c->P > c->tune.fused_update_max_p) HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream));
   else if (c->P >= 2 && !c->tune.update_fused) HIPCHK(c, launch_update_front(u, c->stream));  // option "update": fused one-kernel step
   else HIPCHK(c, launch_update(u, c->stream));

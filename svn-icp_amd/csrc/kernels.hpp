@@ -176,6 +176,7 @@ struct UpdateArgs {
   // SVGD-ICP mode (k_particle_update_svgd)
   double* eul;         // [P][6] optimizer parameters x,y,z,roll,pitch,yaw
   double* opt;         // [3][P][6] optimizer state
+  int svgd;            // 1: SVGD-ICP mode through the workgroup-parallel chain (k_upd_prepare … k_upd_finish)
   int optimizer;       // SVNICP_OPT_*
   double n_src;        // gradient_scaling_factor_ = B (SVGDICP.cpp:58)
   double* uctl;        // multi-workgroup update path: small control / norm area

@@ -438,6 +438,10 @@ __device__ __forceinline__ double* upd_hpart(double* uctl, int P) {  // [ceil(P/
   return uctl + UCTL_NORM + ((P + 7) & ~7) + HB_NB / 2;
 }
 
+// SVGD-ICP pieces shared by the one-workgroup kernel and this chain (defined with k_particle_update_svgd below)
+__device__ void svgd_gradient(const UpdateArgs& a, int p, double* g6);
+__device__ double svgd_step_one(const UpdateArgs& a, int p, const double* phi6, const double* xold6);
+
 __global__ __launch_bounds__(128) void k_upd_prepare(UpdateArgs a) {
   if (a.ctl[0]) return;
   __shared__ double sh_H[128 * 37];
@@ -449,6 +453,15 @@ __global__ __launch_bounds__(128) void k_upd_prepare(UpdateArgs a) {
   if (p == 0) {
     unsigned long long* u = reinterpret_cast<unsigned long long*>(a.uctl);
     u[UCTL_NAN] = 0ull; u[UCTL_TICKET] = 0ull; u[UCTL_CNT] = 0ull;
+  }
+  if (a.svgd) {  // SVGD-ICP: the "Newton" slot carries the first-order gradient, x is pose_particles_ as it stands (SVGDICP.cpp:106-110)
+    if (p < P) {
+      double g6[6];
+      svgd_gradient(a, p, g6);
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { w.N[p * 6 + d] = g6[d]; w.x[p * 6 + d] = a.pose_out[d * P + p]; }
+    }
+    return;
   }
   if (p < P) {
     double Rc[9], H[36], b[6], LU[36], x6[6];
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
   if (blockIdx.x == 1) {
     // second workgroup: mean Hessian from the per-block sums of k_upd_prepare and its inverse (linalg::inv,
     // SVNICP.cpp:225) — a long serial 6x6 LU that the median select should not wait for
-    if (a.full_grad) return;
+    if (a.full_grad || a.svgd) return;   // only the default SVN branch preconditions with the mean Hessian
     if (tid < 36) {
       const double* hp = upd_hpart(a.uctl, P);
       double sacc = 0.0;
@@ -913,6 +926,32 @@ __global__ __launch_bounds__(256) void k_upd_direction(UpdateArgs a) {
   double xi[6], phi[6];
 #pragma unroll
   for (int d = 0; d < 6; ++d) xi[d] = w.x[pi * 6 + d];
+  if (a.svgd) {  // svgd_grad (SVGDICP.cpp:457-474) + optimizer step + pose refresh of this particle (:476-494, :118-121)
+    double gr[6] = {0, 0, 0, 0, 0, 0}, kg[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = part; j < P; j += TPP) {
+      double df[6], sq = 0.0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { df[d] = xi[d] - w.x[j * 6 + d]; sq += df[d] * df[d]; }
+      const double k = exp(-sq / h);
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { gr[d] += df[d] * k; kg[d] += k * (-w.N[j * 6 + d]); }
+    }
+    for (int off = TPP >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { gr[d] += __shfl_xor(gr[d], off, kWave); kg[d] += __shfl_xor(kg[d], off, kWave); }
+    }
+    if (part == 0) {
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { phi[d] = (kg[d] + 2 / h * gr[d]) / P; w.phi[pi * 6 + d] = phi[d]; }
+      a.uctl[UCTL_NORM + pi] = svgd_step_one(a, pi, phi, xi);
+      if (!a.check_early_stop) {  // no stop decision pending: the history row (SVGDICP.cpp:133) can go out now
+        float* hrow = a.history + (size_t)a.iteration * 6 * P;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) hrow[d * P + pi] = (float)a.pose_out[d * P + pi];
+      }
+    }
+    return;
+  }
   if (!a.full_grad) {
     double g[6] = {0, 0, 0, 0, 0, 0}, kn[6] = {0, 0, 0, 0, 0, 0}, ks = 0.0;
     for (int j = part; j < P; j += TPP) {
@@ -999,8 +1038,11 @@ __global__ __launch_bounds__(256) void k_upd_finish(UpdateArgs a) {
   __shared__ double sh_part[256];
   __shared__ int sh_stop;
   if (a.trH) {
-    for (int e = tid; e < P * 36; e += 256) a.trH[e] = w.H[e];
-    for (int e = tid; e < P * 6; e += 256) { a.trb[e] = w.b[e]; a.trN[e] = w.N[e]; a.trphi[e] = w.phi[e]; }
+    if (!a.svgd) {
+      for (int e = tid; e < P * 36; e += 256) a.trH[e] = w.H[e];
+      for (int e = tid; e < P * 6; e += 256) a.trb[e] = w.b[e];
+    }
+    for (int e = tid; e < P * 6; e += 256) { a.trN[e] = w.N[e]; a.trphi[e] = w.phi[e]; }
     if (tid == 0) *a.trh = a.uctl[UCTL_H];
   }
   if (a.check_early_stop) {
@@ -1046,6 +1088,84 @@ __device__ void euler_partials(const double* R0, double roll, double pitch, doub
   mat3_mul(R0, py, dR[2]);
 }
 
+// sgd_grad of one particle from the raw sums (SVGDICP.cpp:398-455): Euler-angle partials, (count + 1) normalisation,
+// scaled by the source size
+__device__ void svgd_gradient(const UpdateArgs& a, int p, double* g6) {
+  const double* s = a.sums + (size_t)p * kNSums;
+  const double* eu = a.eul + 6 * p;
+  double dR[3][9];
+  euler_partials(a.pose.R0, eu[3], eu[4], eu[5], dR);
+  const double cnt1 = s[4] + 1.0;  // nonzero_count + 1
+  const double* R0 = a.pose.R0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)      // error.sum(1).matmul(R0) / (count + 1)
+    g6[j] = ((s[10] * R0[j] + s[11] * R0[3 + j] + s[12] * R0[6 + j]) / cnt1) * a.n_src;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {    // Σ_b e·(dR_k s) = Σ_ij dR_k[i][j]·(Σ_b e_i s_j)
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v += dR[k][3 * i + j] * s[13 + 3 * i + j];
+    g6[3 + k] = (v / cnt1) * a.n_src;
+  }
+}
+
+// optimizer step of one particle (param.grad = -stein_grad, SVGDICP.cpp:476-494 with torch's defaults, :142-170), next
+// epoch's R_, t_, total pose (:88-91) and pose_particles_ (:118-121); returns |new pose - xold| for the early stop (:123-131)
+__device__ double svgd_step_one(const UpdateArgs& a, int p, const double* phi6, const double* xold6) {
+  const int P = a.P;
+  const int step = a.iteration + 1;
+  double n2 = 0.0, e6[6];
+#pragma unroll
+  for (int d = 0; d < 6; ++d) {
+    const int i = p * 6 + d;
+    double g = -phi6[d];
+    double v = a.eul[i];
+    double* m1 = a.opt + i; double* m2 = a.opt + (size_t)6 * P + i; double* m3 = a.opt + (size_t)12 * P + i;
+    switch (a.optimizer) {
+      case 0: {  // Adam: betas (0.9, 0.999), eps 1e-8
+        const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+        const double e1 = b1 * (*m1) + (1 - b1) * g;
+        const double e2 = b2 * (*m2) + (1 - b2) * g * g;
+        *m1 = e1; *m2 = e2;
+        const double bc1 = 1 - pow(b1, (double)step), bc2 = 1 - pow(b2, (double)step);
+        v -= (a.lr / bc1) * (e1 / (sqrt(e2) / sqrt(bc2) + eps));
+      } break;
+      case 1: {  // RMSprop: alpha .99, eps 1e-8, weight_decay 1e-8, momentum .9
+        const double alpha = 0.99, eps = 1e-8, wd = 1e-8, mom = 0.9;
+        g = g + wd * v;
+        const double sq = alpha * (*m1) + (1 - alpha) * g * g;
+        const double buf = mom * (*m2) + g / (sqrt(sq) + eps);
+        *m1 = sq; *m2 = buf;
+        v -= a.lr * buf;
+      } break;
+      case 2: v -= a.lr * g; break;  // SGD
+      default: {  // Adagrad: eps 1e-10
+        const double ss = (*m3) + g * g;
+        *m3 = ss;
+        v -= a.lr * (g / (sqrt(ss) + 1e-10));
+      } break;
+    }
+    a.eul[i] = v;
+    e6[d] = v;
+    const double df = v - xold6[d];
+    n2 += df * df;
+  }
+  // next epoch: R_ = Euler(rx,ry,rz), t_ = (x,y,z) (SVGDICP.cpp:88-91)
+  double Rm[9], Rt[9], tt[3];
+  euler_to_R(e6[3], e6[4], e6[5], Rm);
+  mat3_mul(a.pose.R0, Rm, Rt);
+  mat3_vec(a.pose.R0, e6, tt);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { a.R[9 * p + i] = Rm[i]; a.Rtot[12 * p + i] = Rt[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { a.t[3 * p + i] = e6[i]; a.Rtot[12 * p + 9 + i] = a.pose.t0[i] + tt[i]; }
+#pragma unroll
+  for (int d = 0; d < 6; ++d) a.pose_out[d * P + p] = e6[d];   // pose_particles_ (SVGDICP.cpp:118-121)
+  return sqrt(n2);
+}
+
 __global__ __launch_bounds__(UT) void k_particle_update_svgd(UpdateArgs a) {
   if (a.ctl[0]) return;
   extern __shared__ __align__(16) double dyn[];
@@ -1061,24 +1181,7 @@ __global__ __launch_bounds__(UT) void k_particle_update_svgd(UpdateArgs a) {
 
   // ---- 1. sgd_grad from the raw sums (SVGDICP.cpp:398-455) ----
   for (int p = tid; p < P; p += UT) {
-    const double* s = a.sums + (size_t)p * kNSums;
-    const double* eu = a.eul + 6 * p;
-    double dR[3][9];
-    euler_partials(a.pose.R0, eu[3], eu[4], eu[5], dR);
-    const double cnt1 = s[4] + 1.0;  // nonzero_count + 1
-    const double* R0 = a.pose.R0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)      // error.sum(1).matmul(R0) / (count + 1)
-      lg[p * 6 + j] = ((s[10] * R0[j] + s[11] * R0[3 + j] + s[12] * R0[6 + j]) / cnt1) * a.n_src;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {    // Σ_b e·(dR_k s) = Σ_ij dR_k[i][j]·(Σ_b e_i s_j)
-      double v = 0.0;
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) v += dR[k][3 * i + j] * s[13 + 3 * i + j];
-      lg[p * 6 + 3 + k] = (v / cnt1) * a.n_src;
-    }
+    svgd_gradient(a, p, lg + p * 6);
 #pragma unroll
     for (int d = 0; d < 6; ++d) lx[p * 6 + d] = a.pose_out[d * P + p];
   }
@@ -1127,58 +1230,8 @@ __global__ __launch_bounds__(UT) void k_particle_update_svgd(UpdateArgs a) {
   }
 
   // ---- 3. optimizer step (param.grad = -stein_grad, SVGDICP.cpp:476-494), pose refresh, early stop ----
-  const int step = a.iteration + 1;
   double my_norm = 0.0;
-  for (int p = tid; p < P; p += UT) {
-    double n2 = 0.0, e6[6];
-#pragma unroll
-    for (int d = 0; d < 6; ++d) {
-      const int i = p * 6 + d;
-      double g = -lphi[i];
-      double v = a.eul[i];
-      double* m1 = a.opt + i; double* m2 = a.opt + (size_t)6 * P + i; double* m3 = a.opt + (size_t)12 * P + i;
-      switch (a.optimizer) {
-        case 0: {  // Adam: betas (0.9, 0.999), eps 1e-8
-          const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
-          const double e1 = b1 * (*m1) + (1 - b1) * g;
-          const double e2 = b2 * (*m2) + (1 - b2) * g * g;
-          *m1 = e1; *m2 = e2;
-          const double bc1 = 1 - pow(b1, (double)step), bc2 = 1 - pow(b2, (double)step);
-          v -= (a.lr / bc1) * (e1 / (sqrt(e2) / sqrt(bc2) + eps));
-        } break;
-        case 1: {  // RMSprop: alpha .99, eps 1e-8, weight_decay 1e-8, momentum .9
-          const double alpha = 0.99, eps = 1e-8, wd = 1e-8, mom = 0.9;
-          g = g + wd * v;
-          const double sq = alpha * (*m1) + (1 - alpha) * g * g;
-          const double buf = mom * (*m2) + g / (sqrt(sq) + eps);
-          *m1 = sq; *m2 = buf;
-          v -= a.lr * buf;
-        } break;
-        case 2: v -= a.lr * g; break;  // SGD
-        default: {  // Adagrad: eps 1e-10
-          const double ss = (*m3) + g * g;
-          *m3 = ss;
-          v -= a.lr * (g / (sqrt(ss) + 1e-10));
-        } break;
-      }
-      a.eul[i] = v;
-      e6[d] = v;
-      const double df = v - lx[i];
-      n2 += df * df;
-    }
-    my_norm += sqrt(n2);
-    // next epoch: R_ = Euler(rx,ry,rz), t_ = (x,y,z) (SVGDICP.cpp:88-91)
-    double Rm[9], Rt[9], tt[3];
-    euler_to_R(e6[3], e6[4], e6[5], Rm);
-    mat3_mul(a.pose.R0, Rm, Rt);
-    mat3_vec(a.pose.R0, e6, tt);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { a.R[9 * p + i] = Rm[i]; a.Rtot[12 * p + i] = Rt[i]; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { a.t[3 * p + i] = e6[i]; a.Rtot[12 * p + 9 + i] = a.pose.t0[i] + tt[i]; }
-#pragma unroll
-    for (int d = 0; d < 6; ++d) a.pose_out[d * P + p] = e6[d];   // pose_particles_ (SVGDICP.cpp:118-121)
-  }
+  for (int p = tid; p < P; p += UT) my_norm += svgd_step_one(a, p, lphi + p * 6, lx + p * 6);
   bool stop = false;
   if (a.check_early_stop) {
     for (int off = 32; off > 0; off >>= 1) my_norm += __shfl_xor(my_norm, off, kWave);

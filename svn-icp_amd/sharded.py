@@ -24,7 +24,7 @@ import ctypes as C
 import numpy as np
 
 from . import binding
-from .solver import SVNICP, SteinICPParam, SteinICPState
+from .solver import SVGDICP, SVNICP, SteinICPParam, SteinICPState
 
 
 def shard_range(n: int, world: int, rank: int) -> tuple[int, int]:
@@ -46,11 +46,11 @@ class HipBackend:
 
     record_width = 22
 
-    def __init__(self, param: SteinICPParam, init_pose, device_index: int):
+    def __init__(self, param: SteinICPParam, init_pose, device_index: int, solver_cls=SVNICP):
         import torch
         self.torch = torch
         self.device = torch.device("cuda", device_index)
-        self.solver = SVNICP(param, init_pose, device=device_index)
+        self.solver = solver_cls(param, init_pose, device=device_index)
         self._L = binding.load_library()
         self._h = self.solver.handle
         # one queue for kernels and collectives: run the library on torch's current stream
@@ -132,6 +132,8 @@ def _all_gather_rows(dist, group, full, lo, hi, world, rank):
 class ShardedSVNICP:
     """SVNICP with the same call sequence as the single-GPU class, particles sharded over a process group."""
 
+    _solver_cls = SVNICP
+
     def __init__(self, param: SteinICPParam, init_pose, group=None, device_index: int | None = None, backend=None):
         import torch.distributed as dist
         self.dist = dist
@@ -144,7 +146,7 @@ class ShardedSVNICP:
             import torch
             if device_index is None:
                 device_index = torch.cuda.current_device()
-            backend = HipBackend(param, init_pose, device_index)
+            backend = HipBackend(param, init_pose, device_index, self._solver_cls)
         self.be = backend
 
     def add_cloud(self, src, tgt, init_pose):
@@ -154,6 +156,8 @@ class ShardedSVNICP:
         self.be.set_initial_mean(pose)
 
     def stein_align(self) -> SteinICPState:
+        if self._solver_cls is SVGDICP and self.param.optimizer not in ("Adam", "RMSprop", "SGD", "Adagrad"):
+            return SteinICPState.NO_OPTIMIZER      # set_optimizer() found none: stein_align returns at once (SVGDICP.cpp:73-75)
         be, W, r = self.be, self.world, self.rank
         p_lo, p_hi = shard_range(be.P, W, r)
         b_lo, b_hi = shard_range(be.B, W, r)
@@ -181,3 +185,10 @@ class ShardedSVNICP:
         if name.startswith("get_"):
             return getattr(self.be.solver, name)
         raise AttributeError(name)
+
+
+class ShardedSVGDICP(ShardedSVNICP):
+    """SVGD-ICP (first-order sibling, SVGDICP.cpp:66-140) with the same sharding: the per-particle record is the same 22
+    raw sums (slot 4 carries the inlier count of SVGDICP.cpp:404), and every rank steps the optimizer of ALL particles
+    redundantly after the all-gather, so parameters and optimizer state stay bit-identical across ranks."""
+    _solver_cls = SVGDICP

@@ -103,25 +103,29 @@ def test_zero_rotation_step_gives_nan_left_jacobian(hip, orc, P):
     assert np.array_equal(np.isnan(s.get_cov_matrix()), np.isnan(o.get_cov_matrix()))
 
 
-@pytest.mark.parametrize("P,B,M,opt", [(128, 4096, 16384, "Adam"), (512, 1536, 8192, "RMSprop"), (200, 1000, 4000, "SGD"),
-                                       (130, 800, 3000, "Adagrad")])
-def test_svgd_mode_at_production_particle_counts(hip, orc, P, B, M, opt):
-    """SVGD-ICP (SVGDICP.cpp:66-140, 398-494) with 128…512 particles against the oracle: candidate lists bit-exact,
+@pytest.mark.parametrize("P,B,M,opt,es", [(128, 4096, 16384, "Adam", False), (512, 1536, 8192, "RMSprop", False), (200, 1000, 4000, "SGD", False),
+                                          (130, 800, 3000, "Adagrad", False), (300, 900, 3000, "Adam", True), (1030, 400, 2000, "Adam", False)])
+def test_svgd_mode_at_production_particle_counts(hip, orc, P, B, M, opt, es):
+    """SVGD-ICP (SVGDICP.cpp:66-140, 398-494) with 128…1030 particles (one-workgroup step up to 128, the workgroup-parallel
+    chain above; one case with the early stop firing) against the oracle: candidate lists bit-exact,
     gradients / Stein direction per iteration, final particles, mean and covariance to 1e-9."""
     src, tgt = hip.scans.random_clouds(B, M, seed=P + 1, extent=20.0)
     init = hip.scans.make_particles(P, seed=P) * 0.3
-    cfg = dict(iterations=6, lr=0.01, max_dist=1.0, check_early_stop=False, convergence_threshold=1e-5, knn_count=32,
-               optimizer=opt)
+    cfg = dict(iterations=(30 if es else 6), lr=0.01, max_dist=1.0, check_early_stop=es, convergence_threshold=(0.05 if es else 1e-5),
+               knn_count=32, optimizer=opt)
     o = orc.Solver(init, mode=orc.MODE_SVGD, svn_full_grad=False, **cfg)
     o.add_cloud(src, tgt, init); tro = o.enable_trace(); o.stein_align()
     s = _hip_svgd(hip, init, cfg); s.add_cloud(src, tgt, init); s.set_initial_mean(np.eye(4))
     assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
     assert np.array_equal(s.get_candidates().astype(np.int64), o.candidates())
     tr = s.get_trace()
-    assert np.array_equal(tr["corr"], tro["corr"])
-    assert np.allclose(tr["newton"], tro["newton"], rtol=1e-9, atol=1e-9)
-    assert np.allclose(tr["phi"], tro["phi"], rtol=1e-9, atol=1e-9)
-    assert np.allclose(tr["h"], tro["h"], rtol=1e-10)
+    n = o.iterations_run()
+    assert s.get_iterations_run() == n and int(s.get_runtime()[2]) == o.finish_iter() and (not es or n < cfg["iterations"])
+    assert np.array_equal(tr["corr"][:n], tro["corr"][:n])
+    assert np.allclose(tr["newton"][:n], tro["newton"][:n], rtol=1e-9, atol=1e-9)
+    assert np.allclose(tr["phi"][:n], tro["phi"][:n], rtol=1e-9, atol=1e-9)
+    assert np.allclose(tr["h"][:n], tro["h"][:n], rtol=1e-10)
+    assert np.allclose(s.get_particle_history(), o.get_particle_history(), atol=1e-6)
     for got, want in ((s.get_transformation(), o.get_transformation()), (s.get_distribution(), o.get_distribution()),
                       (s.get_cov_matrix(), o.get_cov_matrix()), (s.get_particles(), o.get_particles())):
         assert np.allclose(got, want, rtol=0, atol=TIGHT)

@@ -428,6 +428,45 @@ def test_two_processes_one_gpu_sharded_driver(hip, tmp_path):
     assert np.allclose(r0["particles"], ref.get_particles(), rtol=0, atol=1e-12)
 
 
+def _two_rank_svgd_worker(rank, world, port, out_dir):
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as graft
+    import torch.distributed as dist
+    pkg = graft.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from svnicp_amd.sharded import ShardedSVGDICP
+    P, B, M = 150, 2001, 9000          # P > 128: the workgroup-parallel SVGD step on every rank; ragged shards
+    src, tgt = pkg.scans.random_clouds(B, M, seed=29, extent=25.0)
+    init = pkg.scans.make_particles(P, seed=29) * 0.3
+    prm = pkg.SteinICPParam(iterations=6, lr=0.01, max_dist=1.0, KNN_count=24, optimizer="Adam")
+    s = ShardedSVGDICP(prm, init, device_index=0)
+    s.add_cloud(src, tgt, init); s.set_initial_mean(np.eye(4)); s.stein_align()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), particles=s.get_particles(), cov=s.get_cov_matrix())
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_processes_one_gpu_sharded_svgd(hip, orc, tmp_path):
+    """SVGD-ICP through the sharded driver (two ranks on cuda:0, gloo): replicas bit-identical, equal to the
+    single-process SVGDICP run and to the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_two_rank_svgd_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = (np.load(str(tmp_path / f"r{r}.npz")) for r in range(2))
+    assert np.array_equal(r0["particles"], r1["particles"]) and np.array_equal(r0["cov"], r1["cov"])
+    P, B, M = 150, 2001, 9000
+    src, tgt = hip.scans.random_clouds(B, M, seed=29, extent=25.0)
+    init = hip.scans.make_particles(P, seed=29) * 0.3
+    cfg = dict(iterations=6, lr=0.01, max_dist=1.0, check_early_stop=False, convergence_threshold=1e-5, knn_count=24, optimizer="Adam")
+    ref = _hip_svgd(hip, init, cfg, trace=False); ref.add_cloud(src, tgt, init); ref.stein_align()
+    assert np.allclose(r0["particles"], ref.get_particles(), rtol=0, atol=1e-12)
+    o = orc.Solver(init, mode=orc.MODE_SVGD, svn_full_grad=False, **cfg); o.add_cloud(src, tgt, init); o.stein_align()
+    assert np.allclose(r0["particles"], o.get_particles(), rtol=0, atol=TIGHT)
+
+
 def _two_rank_nccl_worker(rank, world, port, out_dir):
     import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--correspondence", default="fast", choices=("fast", "full"),
+                    help="full = the reference's get_correspondence (K = 1 over the whole target per particle per iteration; N = 1 only)")
     ap.add_argument("--workload", default=None, help="C1|C2|C3|C4|C5 (default: C3 at N = 1, C4 = 512 particles fixed at N > 1)")
     ap.add_argument("--full-grad", type=int, default=0, help="SVNFullGrad (shipped default false)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
@@ -135,6 +137,8 @@ def main():
                   pkg.SVNICP(prm, init, pkg.ParticleWeightOpt(), device=local_rank))
         if not a.no_profile:
             solver.set_profile(True)
+        if a.correspondence == "full":
+            solver.set_option("correspondence", "full")
     else:
         from svnicp_amd.sharded import ShardedSVNICP
         solver = ShardedSVNICP(prm, init, device_index=local_rank)
@@ -184,7 +188,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo — not a measurement)",
         "config": {"workload": f"{wl}: {P} particles {mode_name}, {B}-pt source vs {M}-pt target, K={K}, I={I}, "
-                               f"max_dist=1.0, lr={prm.lr}, SVNFullGrad={bool(a.full_grad)}, early stop off; synthetic 64-beam "
+                               f"max_dist=1.0, lr={prm.lr}, SVNFullGrad={bool(a.full_grad)}, correspondence={a.correspondence}, early stop off; synthetic 64-beam "
                                f"scans (seed {scans.SEED})",
                    "particles": P, "source_points": B, "target_points": M, "knn_count": K, "iterations": I,
                    "parallelism": "single GPU" if world == 1 else f"{P} particles fixed, sharded {P // world}/GPU; stage A "

@@ -74,6 +74,8 @@ def lib():
         L.orc_get_finish_iter.restype = C.c_int
         L.orc_get_iterations_run.argtypes = [C.c_void_p]
         L.orc_get_iterations_run.restype = C.c_int
+        L.orc_set_correspondence_full.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_correspondence_full.restype = None
         L.orc_get_candidates.argtypes = [C.c_void_p]
         L.orc_get_candidates.restype = ip64
         L.orc_get_candidate_dist2.argtypes = [C.c_void_p]
@@ -260,6 +262,10 @@ class Solver:
 
     def iterations_run(self):
         return self.L.orc_get_iterations_run(self.h)
+
+    def set_correspondence_full(self, on=True):
+        """SVGDICP.cpp:274-298 get_correspondence (K = 1 over the whole target per particle) instead of the fast path."""
+        self.L.orc_set_correspondence_full(self.h, 1 if on else 0)
 
     def candidates(self):
         p = self.L.orc_get_candidates(self.h)

@@ -270,6 +270,7 @@ struct orc_solver {
   double *opt_state;  /* SVGD optimizer state: [3][P][6] */
   int finish_iter;   /* finish_iter_: set in the constructor (SVGDICP.cpp:42) and by SVGDICP::stein_align's early stop only (:128) */
   int iters_run;     /* test tap: iterations the last align executed */
+  int full_corr;     /* 1: get_correspondence (SVGDICP.cpp:274-298) instead of get_correspondence_fast */
   orc_trace tr;
   int has_trace;
 };
@@ -399,6 +400,22 @@ static inline int correspond(const orc_solver *s, const double Rt[9], const doub
   double Ts[3];
   for (int i = 0; i < 3; ++i)
     Ts[i] = (sp[0] * Rt[3 * i] + sp[1] * Rt[3 * i + 1] + sp[2] * Rt[3 * i + 2]) + tt[i];
+  if (s->full_corr) {
+    /* get_correspondence (SVGDICP.cpp:274-298): KNearestNeighborIdx(transformed_source, target, K = 1) over the WHOLE target
+     * in index order (knn_cpu.cpp: size < K || dist < top, strict), then the same point_filter; kbest = the target index */
+    int64_t bi = 0;
+    double bdist = 0;
+    for (int64_t j = 0; j < s->M; ++j) {
+      double dist = 0;
+      for (int d = 0; d < 3; ++d) { const double diff = Ts[d] - s->tgt[3 * j + d]; dist += diff * diff; }
+      if (j == 0 || dist < bdist) { bdist = dist; bi = j; }
+    }
+    const int mm = bdist < s->prm.max_dist;
+    const double mff = mm ? 1.0 : 0.0;
+    for (int d = 0; d < 3; ++d) { sm[d] = mff * sp[d]; Tm[d] = mff * Ts[d]; qm[d] = mff * s->tgt[3 * bi + d]; }
+    *kbest = (int)bi;
+    return mm;
+  }
   const double *c = s->cand_xyz + (size_t)b * s->K * 3;
   int best = 0;
   double bd = 0;
@@ -903,5 +920,6 @@ void orc_get_particle_history(orc_solver *s, float *out) {
 }
 int orc_get_finish_iter(orc_solver *s) { return s->finish_iter; }
 int orc_get_iterations_run(orc_solver *s) { return s->iters_run; }
+void orc_set_correspondence_full(orc_solver *s, int on) { s->full_corr = on ? 1 : 0; }
 const int64_t *orc_get_candidates(orc_solver *s) { return s->cand_idx; }
 const double *orc_get_candidate_dist2(orc_solver *s) { return s->cand_d2; }

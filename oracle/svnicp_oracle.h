@@ -97,6 +97,9 @@ void orc_get_particle_weight(orc_solver *s, double *outP);      /* SVNICP.cpp:28
 void orc_get_particle_history(orc_solver *s, float *outIx6P);   /* SVGDICP.cpp:526-534 */
 int orc_get_finish_iter(orc_solver *s);      /* finish_iter_ as the reference keeps it (SVGDICP.cpp:42,128) */
 int orc_get_iterations_run(orc_solver *s);   /* test tap: iterations the last align executed */
+/* 1: correspondences by the reference's get_correspondence (SVGDICP.cpp:274-298, K = 1 over the whole target per
+ * particle; dead code upstream, kept as the optional mode of SURVEY.md §8 a20); trace corr then holds target indices */
+void orc_set_correspondence_full(orc_solver *s, int on);
 /* candidate indices of the last align: [B][K] int64 (sourceKNN_idx_, SVGDICP.cpp:214) */
 const int64_t *orc_get_candidates(orc_solver *s);
 const double *orc_get_candidate_dist2(orc_solver *s);

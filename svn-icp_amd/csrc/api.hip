@@ -84,6 +84,8 @@ struct svnicp_ctx {
   DevBuf<int> ctl;
   int hist_I = 0, hist_P = 0;
   Tuning tune{};
+  DevBuf<double> full_q, full_d2;      // correspondence = full: one particle's transformed source, its nearest distances
+  DevBuf<int32_t> full_idx;            // … and the nearest target of every (particle of the shard, source point): [P][B]
   unsigned long long* dbg_phase = nullptr;   // debug option: per-phase wave cycles of k_knn_tiles (per context, per device)
   unsigned long long* dbg_upd = nullptr;     // debug option: phase cycles of k_particle_update
   int finish_iter = 0;   // finish_iter_: constructor value, changed only by an SVGD-mode early stop (SVGDICP.cpp:42,128)
@@ -224,6 +226,7 @@ void svnicp_destroy(svnicp_ctx* c) {
   for (auto* b : dbl) b->release();
   c->eul.release(); c->opt.release(); c->uctl.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
+  c->full_q.release(); c->full_d2.release(); c->full_idx.release();
   c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->tail.release(); c->kbest.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   if (c->dbg_phase) (void)hipFree(c->dbg_phase);
   if (c->dbg_upd) (void)hipFree(c->dbg_upd);
@@ -359,6 +362,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "wgpcu") { int x = 0, y = 0; ok = sscanf(v.c_str(), "%d,%d", &x, &y) == 2 && x >= 0 && x <= 16 && y >= 0 && y <= 16; if (ok) { t.wgpcu_search = x; t.wgpcu_accum = y; } }
   else if (k == "tp") ok = num(0, 1 << 16, &t.tp);
   else if (k == "debug") ok = num(0, 1, &t.debug);
+  else if (k == "correspondence") { if (v == "fast") t.full_corr = 0; else if (v == "full") t.full_corr = 1; else ok = false; }
   else return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: unknown option '" + k + "'");
   if (!ok) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: bad value '" + v + "' for option '" + k + "'");
   c->have_candidates = false;
@@ -503,36 +507,35 @@ static hipError_t launch_fallback(svnicp_ctx* c, KnnArgs a) {
   a.slice_max_queries = c->sliced_max; a.slices = 0;
   hipError_t e = launch_knn_topk(a, c->stream);  // returns at once unless the list is longer than slice_max_queries
   if (e != hipSuccess || c->sliced_max <= 0) return e;
-  a.slices = knn_slice_count(c->K);
+  a.slices = knn_slice_count(a.K);
   a.merge_n = 1;
-  while (a.merge_n < a.slices * c->K) a.merge_n <<= 1;
+  while (a.merge_n < a.slices * a.K) a.merge_n <<= 1;
   a.sl_d = c->sl_d.p; a.sl_i = c->sl_i.p;
   e = launch_knn_topk(a, c->stream);
   if (e != hipSuccess) return e;
   return launch_knn_merge_slices(a, c->stream);
 }
 
-int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
-  CTX_CHECK(c);
-  if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_stage_candidates: call svnicp_align_begin first");
-  if (b_lo < 0 || b_hi > c->B || b_lo > b_hi) return fail(c, SVNICP_ERR_INVALID, "svnicp_stage_candidates: bad row range");
-  if (bind(c)) return SVNICP_ERR_HIP;
+// exact top-K of pose·qsrc[b_lo, b_hi) against the whole target into out_idx / out_d2 ([rows][K]); K = the context's K for
+// stage A, K = 1 for the per-particle search of correspondence = full (there the seeded-scan variant, whose plan is built
+// for the context's K, is not used)
+static int stage_a(svnicp_ctx* c, const double* qsrc, const Pose0& pose, int K, int32_t* out_idx, double* out_d2, int64_t b_lo,
+                   int64_t b_hi) {
   KnnArgs a{};
-  a.src = c->src.p; a.pose = c->pose0; a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p; a.torig = c->torig.p;
-  a.M = c->M; a.Mp = c->Mp; a.b_lo = b_lo; a.b_hi = b_hi; a.K = c->K; a.S = c->S;
-  a.pool_d = c->pool_d.p; a.pool_i = c->pool_i.p; a.out_idx = c->cand_idx.p; a.out_d2 = c->cand_d2.p;
-  HIPCHK(c, prof_begin(c, KC_KNN));
+  a.src = qsrc; a.pose = pose; a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p; a.torig = c->torig.p;
+  a.M = c->M; a.Mp = c->Mp; a.b_lo = b_lo; a.b_hi = b_hi; a.K = K; a.S = knn_pool_size(K);
+  a.pool_d = c->pool_d.p; a.pool_i = c->pool_i.p; a.out_idx = out_idx; a.out_d2 = out_d2;
   if (c->knn_variant == 2) {
     const int64_t n = b_hi - b_lo;
     if (n > 0) {
-      HIPCHK(c, launch_morton_order(c->src.p, b_lo, n, 1, c->pose0, c->bbox.p, c->keys_a.p, c->keys_b.p, c->vals_a.p,
+      HIPCHK(c, launch_morton_order(qsrc, b_lo, n, 1, pose, c->bbox.p, c->keys_a.p, c->keys_b.p, c->vals_a.p,
                                     c->qorder.p + b_lo, c->sort_tmp.p, c->sort_tmp_bytes, c->stream));
       KnnTilesArgs k{};
-      k.src = c->src.p; k.pose = c->pose0; k.qorder = c->qorder.p + b_lo;
+      k.src = qsrc; k.pose = pose; k.qorder = c->qorder.p + b_lo;
       k.tx = c->tx.p; k.ty = c->ty.p; k.tz = c->tz.p; k.txf = c->txf.p; k.tyf = c->tyf.p; k.tzf = c->tzf.p;
       k.torig = c->torig.p; k.tile_box = c->tile_box.p; k.emax_bits = c->emax.p;
-      k.M = c->M; k.Mp = c->Mp; k.n_tiles = (int)(c->Mp / 512); k.b_lo = b_lo; k.b_hi = b_hi; k.K = c->K; k.S2 = c->scan_S2;
-      k.pool = c->pool2.p; k.out_idx = c->cand_idx.p; k.out_d2 = c->cand_d2.p;
+      k.M = c->M; k.Mp = c->Mp; k.n_tiles = (int)(c->Mp / 512); k.b_lo = b_lo; k.b_hi = b_hi; k.K = K; k.S2 = c->scan_S2;
+      k.pool = c->pool2.p; k.out_idx = out_idx; k.out_d2 = out_d2;
       k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p; k.fail_tau = c->fail_tau.p; k.qrec = c->qrec.p;
       a.qthr = c->fail_tau.p;
       if (c->prm.record_trace) { HIPCHK(c, c->stat_n.ensure((size_t)c->B)); k.stat_n = c->stat_n.p; }
@@ -567,23 +570,36 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
       }
       HIPCHK(c, launch_fallback(c, a));
     }
-  } else if (c->use_scan) {
+  } else if (c->use_scan && K == c->K) {
     KnnScanArgs k{};
-    k.src = c->src.p; k.pose = c->pose0; k.tx = c->tx.p; k.ty = c->ty.p; k.tz = c->tz.p;
+    k.src = qsrc; k.pose = pose; k.tx = c->tx.p; k.ty = c->ty.p; k.tz = c->tz.p;
     k.txf = c->txf.p; k.tyf = c->tyf.p; k.tzf = c->tzf.p; k.torig = c->torig.p; k.emax_bits = c->emax.p;
-    k.M = c->M; k.Mp = c->Mp; k.Ms = c->scan_Ms; k.b_lo = b_lo; k.b_hi = b_hi; k.K = c->K; k.S2 = c->scan_S2;
-    k.seed_rank = c->scan_rank; k.pool = c->pool2.p; k.out_idx = c->cand_idx.p; k.out_d2 = c->cand_d2.p;
+    k.M = c->M; k.Mp = c->Mp; k.Ms = c->scan_Ms; k.b_lo = b_lo; k.b_hi = b_hi; k.K = K; k.S2 = c->scan_S2;
+    k.seed_rank = c->scan_rank; k.pool = c->pool2.p; k.out_idx = out_idx; k.out_d2 = out_d2;
     k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p;
     HIPCHK(c, hipMemsetAsync(c->fail_count.p, 0, sizeof(int), c->stream));
     HIPCHK(c, launch_knn_scan(k, c->stream));
     // redo the (rare) queries whose seeded threshold was too tight: streaming kernel, list mode
     HIPCHK(c, launch_fallback(c, a));
   } else {
+    if (c->knn_variant != 0) return fail(c, SVNICP_ERR_INVALID, "correspondence = full needs knn_count <= 128 (Morton-tile stage A) or knn = v1");
     HIPCHK(c, launch_knn_topk(a, c->stream));
   }
+  return SVNICP_OK;
+}
+
+int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
+  CTX_CHECK(c);
+  if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_stage_candidates: call svnicp_align_begin first");
+  if (b_lo < 0 || b_hi > c->B || b_lo > b_hi) return fail(c, SVNICP_ERR_INVALID, "svnicp_stage_candidates: bad row range");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  HIPCHK(c, prof_begin(c, KC_KNN));
+  const int rc = stage_a(c, c->src.p, c->pose0, c->K, c->cand_idx.p, c->cand_d2.p, b_lo, b_hi);
+  if (rc) return rc;
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;
 }
+
 
 int svnicp_build_candidate_table(svnicp_ctx* c) {
   CTX_CHECK(c);
@@ -615,7 +631,23 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
   a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;
   a.svgd = c->prm.mode == SVNICP_MODE_SVGD ? 1 : 0;
-  if (c->plan.f32 == 3) {
+  if (c->tune.full_corr) {
+    // correspondence = full (the reference's get_correspondence, SVGDICP.cpp:274-298): every particle's transformed source
+    // against the WHOLE target, K = 1 — P exact nearest-neighbour searches per iteration through the stage-A machinery
+    if (c->plan.f32 != 3) return fail(c, SVNICP_ERR_INVALID, "correspondence = full needs the split stage B (accum = split, more than 8 particles or knn_count <= 128)");
+    HIPCHK(c, c->full_q.ensure((size_t)c->B * 3)); HIPCHK(c, c->full_d2.ensure((size_t)c->B));
+    HIPCHK(c, c->full_idx.ensure((size_t)c->P * c->B));
+    Pose0 ident{};
+    ident.R0[0] = ident.R0[4] = ident.R0[8] = 1.0;
+    HIPCHK(c, prof_begin(c, KC_SEARCH));
+    for (int p = c->p_lo; p < c->p_hi; ++p) {
+      HIPCHK(c, launch_transform_cloud(c->src.p, c->B, c->Rtot.p + 12 * (size_t)p, c->full_q.p, c->ctl.p, c->stream));
+      const int rc = stage_a(c, c->full_q.p, ident, 1, c->full_idx.p + (size_t)p * c->B, c->full_d2.p, 0, c->B);
+      if (rc) return rc;
+    }
+    HIPCHK(c, prof_end(c));
+    a.full_idx = c->full_idx.p;
+  } else if (c->plan.f32 == 3) {
     HIPCHK(c, prof_begin(c, KC_SEARCH));
     HIPCHK(c, launch_search_split(c->plan, a, c->stream));
     HIPCHK(c, prof_end(c));

@@ -124,6 +124,7 @@ struct AccumArgs {
   const float4* tail;   // [B][4] float32 local rows of candidates 96..99 (K in 97..100: scored by the VALU, see stein_split.hip)
   int64_t M;
   uint8_t* kbest;       // split variant: winner index per (source point, particle of the shard), [B][Ppad]
+  const int32_t* full_idx;  // correspondence = full: nearest target index of every (particle, source point), [P][B]; else nullptr
   int pts_per_block, spts_per_block;  // split variant: source points per workgroup (accumulate / search kernel)
 };
 struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem;
@@ -141,6 +142,7 @@ struct Tuning {
   int wgpcu_search = 0, wgpcu_accum = 0;   // workgroups per CU the stage-B grids are sized for (0 = automatic)
   int tp = 0;                    // fused stage-B variants: source points per LDS tile (0 = automatic)
   int debug = 0;                 // print plans and per-phase cycle counters to stderr
+  int full_corr = 0;             // 1: correspondence = full — per-particle exact NN over the whole target (SVGDICP.cpp:274-298)
 };
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune);
 int mfma_occupancy_blocks(int PW, int WP, int K, size_t smem);
@@ -154,6 +156,8 @@ hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const doubl
 hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
                                float4* tablef, float* cmax, hipStream_t st);
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st);
+// q[b] = (s·R^T) + t with the stage-B expression (SVNICP.cpp:62-64); pose12 = device [R row-major | t]
+hipError_t launch_transform_cloud(const double* src, int64_t B, const double* pose12, double* q, const int* ctl, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles,
                                   double* sums, const int* ctl, hipStream_t st);
 

@@ -447,7 +447,8 @@ static int occupancy_blocks(const AccumPlan& pl) {
 
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune) {
   AccumPlan pl{};
-  if (f32 >= 2 && (K > 128 || n_particles <= 8)) f32 = 1;  // MFMA tiles: 16 particles wide, 128 candidate rows
+  // MFMA tiles: 16 particles wide, 128 candidate rows; correspondence = full keeps the split accumulate kernel for any particle count
+  if (f32 >= 2 && (K > 128 || (n_particles <= 8 && !tune.full_corr))) f32 = 1;
   pl.f32 = f32;
   int PW = f32 >= 2 ? 16 : 8;
   while (PW < 64 && PW < n_particles) PW <<= 1;

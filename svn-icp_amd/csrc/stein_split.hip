@@ -581,9 +581,12 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
   // is requested back to back, so a trip pays the byte -> index -> coordinates chain once for U points, and nothing is
   // carried between trips except the U prefetched bytes (no rotating copies).  Rows are clamped, never predicated: a
   // point past the block only changes `on`.
-  auto load_kb = [&](int64_t n) -> int {
+  const int32_t* fullp = (!PLAIN && a.full_idx) ? a.full_idx + (size_t)(pvalid ? p : a.p_lo) * a.B : nullptr;
+  auto load_kb = [&](int64_t n) -> int {   // winner byte; correspondence = full: the target index itself
     const int64_t b = n + bs;
-    return (int)kbp[(size_t)(b < blk_hi ? b : blk_lo) * a.Ppad];
+    const int64_t bc = b < blk_hi ? b : blk_lo;
+    if (!PLAIN && fullp) return fullp[bc];
+    return (int)kbp[(size_t)bc * a.Ppad];
   };
   // The reference zeroes a rejected row by multiplying with the mask (SVGDICP.cpp:331-333): e = 0, |e| = 0, so w = 1 and
   // J = [R | 0] — the same products are formed here (mf = 0 or 1), which also makes the pair branch-free.
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
       kb[u] = kbn[u];
       const int64_t b = n + u * STEP + bs;
       const int64_t bl = b < blk_hi ? b : blk_lo;
-      const int64_t t = ccand[(size_t)bl * K + kb[u]];
+      const int64_t t = (!PLAIN && fullp) ? (int64_t)kb[u] : (int64_t)ccand[(size_t)bl * K + kb[u]];
       ti[u] = t < 0 ? 0 : (t >= a.M ? a.M - 1 : t);
     }
 #pragma unroll
@@ -701,7 +704,7 @@ hipError_t launch_srb(const AccumPlan& plan, const AccumArgs& a, hipStream_t st)
 }
 template <int PW, int WP>
 hipError_t launch_w(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
-  if (!a.svgd && !a.corr) hipLaunchKernelGGL((k_stein_accumulate_w<PW, WP, true>), dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
+  if (!a.svgd && !a.corr && !a.full_idx) hipLaunchKernelGGL((k_stein_accumulate_w<PW, WP, true>), dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
   else hipLaunchKernelGGL((k_stein_accumulate_w<PW, WP, false>), dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
   return hipGetLastError();
 }
@@ -755,6 +758,23 @@ hipError_t launch_search_split(const AccumPlan& plan, AccumArgs a, hipStream_t s
       if (plan.WP == 2) return launch_srb<64, 2>(plan, a, st);
       return launch_srb<64, 4>(plan, a, st);
   }
+}
+
+__global__ __launch_bounds__(256) void k_transform_cloud(const double* __restrict__ src, int64_t B, const double* __restrict__ pose12,
+                                                         double* __restrict__ q, const int* __restrict__ ctl) {
+  if (ctl[0]) return;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double s0 = src[3 * b], s1 = src[3 * b + 1], s2 = src[3 * b + 2];
+  q[3 * b] = (s0 * pose12[0] + s1 * pose12[1] + s2 * pose12[2]) + pose12[9];        // SVNICP.cpp:62-64, as in the stage-B kernels
+  q[3 * b + 1] = (s0 * pose12[3] + s1 * pose12[4] + s2 * pose12[5]) + pose12[10];
+  q[3 * b + 2] = (s0 * pose12[6] + s1 * pose12[7] + s2 * pose12[8]) + pose12[11];
+}
+
+hipError_t launch_transform_cloud(const double* src, int64_t B, const double* pose12, double* q, const int* ctl, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_transform_cloud, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, src, B, pose12, q, ctl);
+  return hipGetLastError();
 }
 
 hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {

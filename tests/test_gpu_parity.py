@@ -164,6 +164,52 @@ def test_hip_vs_oracle(hip, orc, P, B, M, K, I, full, es, thr, md, lr):
     _compare(s, o, tro, P)
 
 
+
+# ------------------------------------------------------------------ correspondence = full
+@pytest.mark.parametrize("P,B,M,K,I,full,md,knn", [
+    (4, 300, 1000, 10, 5, False, 1.0, None),       # few particles
+    (20, 777, 5000, 16, 4, True, 1.0, None),       # ragged source, full SVN branch
+    (70, 512, 2048, 32, 3, False, 0.05, None),     # point_filter masks most rows
+    (12, 400, 3000, 8, 3, False, 1.0, "v1"),       # streaming stage A carries the K = 1 searches
+    (130, 260, 900, 8, 2, False, 1.0, None),       # workgroup-parallel Stein step
+    (3, 65, 40, 64, 3, False, 1.0, None),          # M < K
+])
+def test_full_correspondence_mode(hip, orc, P, B, M, K, I, full, md, knn):
+    """The reference's get_correspondence (SVGDICP.cpp:274-298): every particle searches the whole target, K = 1.
+    Trace corr holds target indices (bit-exact against the oracle's brute force); pose to 1e-9."""
+    src, tgt = hip.scans.random_clouds(B, M, seed=3 * P + B)
+    init = hip.scans.make_particles(P, seed=P) * 0.3
+    R0, t0 = hip.scans.rot_zyx(0.001, 0.002, -0.001), np.array([0.01, -0.02, 0.005])
+    cfg = dict(iterations=I, lr=1.0, max_dist=md, check_early_stop=False, convergence_threshold=1e-5, knn_count=K,
+               svn_full_grad=full)
+    o = orc.Solver(init, **cfg)
+    o.set_correspondence_full(True)
+    o.add_cloud(src, tgt, init); o.set_initial_mean(R0, t0)
+    tro = o.enable_trace(); o.stein_align()
+    s = _hip_solver(hip, init, **cfg)
+    s.set_option("correspondence", "full")
+    if knn:
+        s.set_option("knn", knn)
+    s.add_cloud(src, tgt, init); s.set_initial_mean((R0, t0))
+    assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+    assert tro["corr"].max() >= K or M <= K          # really target indices, not positions in the K list
+    _compare(s, o, tro, P)
+    # and the fast mode on the same inputs differs somewhere (K nearest of the INITIAL pose are not always enough)
+    s.set_option("correspondence", "fast")
+    assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+
+
+def test_full_correspondence_mode_refusals(hip):
+    src, tgt = hip.scans.random_clouds(300, 2000, seed=5)
+    init = hip.scans.make_particles(4, seed=1) * 0.1
+    s = _hip_solver(hip, init, iterations=2, lr=1.0, max_dist=1.0, knn_count=200)      # K > 128: seeded-scan stage A
+    s.set_option("correspondence", "full")
+    s.add_cloud(src, tgt, init)
+    with pytest.raises(Exception):
+        s.stein_align()
+    with pytest.raises(Exception):
+        s.set_option("correspondence", "sometimes")
+
 # ------------------------------------------------------------------ stage A variants
 @pytest.mark.parametrize("B,M,K", [(700, 20000, 7), (300, 9000, 1), (1000, 16384, 128), (513, 8192, 100), (64, 40000, 33),
                                    (900, 12000, 150)])

@@ -85,6 +85,8 @@ struct svnicp_ctx {
   int hist_I = 0, hist_P = 0;
   Tuning tune{};
   DevBuf<double> full_q, full_d2;      // correspondence = full: one particle's transformed source, its nearest distances
+  DevBuf<int32_t> arena, chunk_tab;    // stage A (Morton tiles): overflow chunks of the survivor pools and their table
+  int arena_cap = 0;
   DevBuf<int32_t> full_idx;            // … and the nearest target of every (particle of the shard, source point): [P][B]
   unsigned long long* dbg_phase = nullptr;   // debug option: per-phase wave cycles of k_knn_tiles (per context, per device)
   unsigned long long* dbg_upd = nullptr;     // debug option: phase cycles of k_particle_update
@@ -226,7 +228,7 @@ void svnicp_destroy(svnicp_ctx* c) {
   for (auto* b : dbl) b->release();
   c->eul.release(); c->opt.release(); c->uctl.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
-  c->full_q.release(); c->full_d2.release(); c->full_idx.release();
+  c->full_q.release(); c->full_d2.release(); c->full_idx.release(); c->arena.release(); c->chunk_tab.release();
   c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->tail.release(); c->kbest.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   if (c->dbg_phase) (void)hipFree(c->dbg_phase);
   if (c->dbg_upd) (void)hipFree(c->dbg_upd);
@@ -362,6 +364,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "wgpcu") { int x = 0, y = 0; ok = sscanf(v.c_str(), "%d,%d", &x, &y) == 2 && x >= 0 && x <= 16 && y >= 0 && y <= 16; if (ok) { t.wgpcu_search = x; t.wgpcu_accum = y; } }
   else if (k == "tp") ok = num(0, 1 << 16, &t.tp);
   else if (k == "debug") ok = num(0, 1, &t.debug);
+  else if (k == "scan_split") ok = num(0, 16, &t.scan_split);
   else if (k == "correspondence") { if (v == "fast") t.full_corr = 0; else if (v == "full") t.full_corr = 1; else ok = false; }
   else return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: unknown option '" + k + "'");
   if (!ok) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: bad value '" + v + "' for option '" + k + "'");
@@ -426,8 +429,17 @@ int svnicp_align_begin(svnicp_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (ensure_target_layout(c)) return c->err.empty() ? SVNICP_ERR_HIP : SVNICP_ERR_HIP;
   if (c->knn_variant != 0) {
-    if (c->knn_variant == 2) c->scan_S2 = 8192;  // deep global pool (32 KB per query: 288 GB HBM); the select phase tightens before it ranks
-    HIPCHK(c, c->pool2.ensure((size_t)B * c->scan_S2));
+    if (c->knn_variant == 2) {
+      // survivors of the f32 pre-filter: 512 slots per query (median 127 at C3) + a shared arena of 512-slot chunks for the
+      // heavy tail (C3: 0.4 % of the queries, 0.17 M entries; C5: 4 %, 3.1 M entries, up to 9016 per query)
+      c->scan_S2 = kTilesBase + kTilesChunks * kTilesChunk;
+      c->arena_cap = (int)std::max<int64_t>(32768, B / 4);
+      HIPCHK(c, c->pool2.ensure((size_t)B * kTilesBase));
+      HIPCHK(c, c->arena.ensure((size_t)c->arena_cap * kTilesChunk));
+      HIPCHK(c, c->chunk_tab.ensure((size_t)B * kTilesChunks + 16 + (size_t)(B + 63) / 64 + 1));
+    } else {
+      HIPCHK(c, c->pool2.ensure((size_t)B * c->scan_S2));
+    }
     HIPCHK(c, c->fail_list.ensure((size_t)B));
     HIPCHK(c, c->fail_count.ensure(1));
     HIPCHK(c, c->fail_tau.ensure((size_t)B));
@@ -536,6 +548,9 @@ static int stage_a(svnicp_ctx* c, const double* qsrc, const Pose0& pose, int K, 
       k.torig = c->torig.p; k.tile_box = c->tile_box.p; k.emax_bits = c->emax.p;
       k.M = c->M; k.Mp = c->Mp; k.n_tiles = (int)(c->Mp / 512); k.b_lo = b_lo; k.b_hi = b_hi; k.K = K; k.S2 = c->scan_S2;
       k.pool = c->pool2.p; k.out_idx = out_idx; k.out_d2 = out_d2;
+      k.arena = c->arena.p; k.chunk_tab = c->chunk_tab.p; k.arena_cap = c->arena_cap; k.tab_rows = c->B;
+      k.scan_split = c->tune.scan_split == 4 ? 4 : 8;
+      HIPCHK(c, hipMemsetAsync(c->chunk_tab.p, 0xff, ((size_t)c->B * kTilesChunks + 16 + (size_t)(c->B + 63) / 64 + 1) * sizeof(int32_t), c->stream));
       k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p; k.fail_tau = c->fail_tau.p; k.qrec = c->qrec.p;
       a.qthr = c->fail_tau.p;
       if (c->prm.record_trace) { HIPCHK(c, c->stat_n.ensure((size_t)c->B)); k.stat_n = c->stat_n.p; }
@@ -552,19 +567,19 @@ static int stage_a(svnicp_ctx* c, const double* qsrc, const Pose0& pose, int K, 
         std::vector<unsigned long long> h(8 + 8 * dbg_waves);
         HIPCHK(c, hipMemcpyAsync(h.data(), dbg_phase, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        fprintf(stderr, "[svnicp] k_knn_tiles wave cycles: rank %llu seed %llu scan %llu select-rest %llu | select: gather+compact %llu sort %llu output %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+        fprintf(stderr, "[svnicp] k_knn_tiles wave cycles: rank %llu seed %llu scan %llu barrier waits + hand-over %llu | counts: seed tiles %llu scan tiles %llu scan (query, tile) pairs %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
         std::vector<std::pair<unsigned long long, size_t>> tot;
         for (size_t w = 0; w < dbg_waves; ++w) {
           unsigned long long t = 0;
-          for (int i = 0; i < 7; ++i) t += h[8 + 8 * w + i];
+          for (int i = 0; i < 4; ++i) t += h[8 + 8 * w + i];
           tot.push_back({t, w});
         }
         std::sort(tot.begin(), tot.end());
         auto show = [&](const char* tag, size_t k) {
           const size_t w = tot[k].second;
           const unsigned long long* r = &h[8 + 8 * w];
-          fprintf(stderr, "[svnicp]   %s wave %zu: total %llu = rank %llu seed %llu scan %llu gather %llu sort %llu | survivors %llu\n", tag, w,
-                  tot[k].first, r[0], r[1], r[2], r[4], r[5], r[7]);
+          fprintf(stderr, "[svnicp]   %s wave %zu: total %llu = rank %llu seed %llu scan %llu wait %llu | seed tiles %llu scan tiles %llu (query, tile) pairs %llu survivors %llu\n", tag, w,
+                  tot[k].first, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
         };
         if (!tot.empty()) { show("median", tot.size() / 2); show("p90   ", tot.size() * 9 / 10); show("p99   ", tot.size() * 99 / 100); show("max   ", tot.size() - 1); }
       }

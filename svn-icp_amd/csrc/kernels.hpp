@@ -73,8 +73,13 @@ struct KnnTilesArgs {
   int64_t M, Mp;
   int n_tiles;
   int64_t b_lo, b_hi;
-  int K, S2;
-  int32_t* pool;                  // [B][S2]
+  int K, S2;                      // S2 = most survivors a query may hold: kTilesBase + kTilesChunks * kTilesChunk
+  int32_t* pool;                  // [B][kTilesBase]: the first survivors of each query position
+  int32_t* arena;                 // [arena_cap][kTilesChunk]: overflow chunks, handed out on demand to the few heavy queries
+  int32_t* chunk_tab;             // [B][kTilesChunks] chunk id per (query position, chunk), -1 = none; [B*kTilesChunks] = allocation counter (starts at -1)
+  int arena_cap;
+  int64_t tab_rows;               // B of the allocation (rows of chunk_tab); after the table: the chunk allocation counter
+  int scan_split;                 // waves per 64-query workgroup of the scan kernel: 4 or 8
   int32_t* out_idx;
   double* out_d2;
   int32_t* fail_list;
@@ -84,6 +89,7 @@ struct KnnTilesArgs {
   void* qrec;         // [B] 48-byte per-query records (position, threshold, survivor count) between the two kernels
   double* fail_tau;   // optional [B]: a valid threshold (>= K-th distance) of each failed query, +inf if none
 };
+constexpr int kTilesBase = 512, kTilesChunk = 512, kTilesChunks = 15;   // 512 + 15 * 512 = 8192 survivors per query at most
 bool knn_tiles_applicable(int64_t Mp, int K);
 hipError_t launch_knn_tiles(const KnnTilesArgs& a, hipStream_t st);
 size_t sort_temp_bytes(size_t n);
@@ -141,6 +147,7 @@ struct Tuning {
   int fused_update_max_p = 128;  // above this the Stein step runs as workgroup-parallel kernels
   int wgpcu_search = 0, wgpcu_accum = 0;   // workgroups per CU the stage-B grids are sized for (0 = automatic)
   int tp = 0;                    // fused stage-B variants: source points per LDS tile (0 = automatic)
+  int scan_split = 0;            // stage A scan: waves per 64-query workgroup, 4 or 8 (0 = default)
   int debug = 0;                 // print plans and per-phase cycle counters to stderr
   int full_corr = 0;             // 1: correspondence = full — per-particle exact NN over the whole target (SVGDICP.cpp:274-298)
 };

@@ -16,7 +16,7 @@
 //  2. scan   Tiles whose box-to-box lower bound exceeds the wave's largest threshold are skipped
 //     (one vector test per 64 tiles); inside a kept tile, queries whose point-to-box bound exceeds
 //     their own threshold are skipped (one vector test per tile).  The surviving (query, tile)
-//     pairs run the f32 pre-filter loop of knn_scan.hip; survivors go to the wave queue / pools.
+//     pairs run the f32 pre-filter loop of knn_scan.hip; survivors go to the per-query pools.
 //  3. select exact f64 d² of the pool; when a query has many survivors its threshold is first
 //     tightened from the survivors themselves (same two-minima guarantee); keep d² <= τ, bitonic
 //     sort by (d², original index), write the K best to the query's ORIGINAL row.  Pool overflow
@@ -105,7 +105,15 @@ __device__ __forceinline__ float box_lb2(float alo0, float alo1, float alo2, flo
 }
 
 // per-query record handed from k_knn_tiles (rank / seed / scan) to k_knn_select
-struct alignas(16) QRec { double x, y, z, tau; int cnt; int row; int pad0, pad1; };
+struct alignas(16) QRec { double x, y, z, tau; int cnt; int row; float thr, tb; };  // thr / tb: f32 pre-filter and point-to-box thresholds
+
+// survivor e of query position r: the first kTilesBase live in the query's own row, the rest in chunks of the shared arena
+__device__ __forceinline__ int pool_read(const KnnTilesArgs& a, int64_t r, int e) {
+  if (e < kTilesBase) return a.pool[r * kTilesBase + e];
+  const int o = e - kTilesBase;
+  const int id = a.chunk_tab[r * kTilesChunks + (o / kTilesChunk)];
+  return a.arena[(int64_t)id * kTilesChunk + (o % kTilesChunk)];
+}
 
 // select: exact f64 distances of the survivors of query position r, keep d² <= tau, order by (d², original
 // index), write the K best to the query's original row.  One wave; sd/si = SL-entry LDS scratch of that wave.
@@ -120,6 +128,7 @@ __device__ void select_query(const KnnTilesArgs& a, int64_t r, const QRec& rec, 
   bool ok = n <= S2;
   int m = 0;
   constexpr int NBR = 8;  // survivor batches of 64 held in registers
+  static_assert(NBR * kWave == kTilesBase, "the register path reads the query's own pool row only");
   if (ok && n <= NBR * kWave) {
     // common case: every survivor's slot, then every survivor's coordinates, are requested back to back —
     // two memory round trips per query instead of two per 64 survivors — and d² stays in registers
@@ -128,7 +137,7 @@ __device__ void select_query(const KnnTilesArgs& a, int64_t r, const QRec& rec, 
 #pragma unroll
     for (int j = 0; j < NBR; ++j) {
       const int e = j * kWave + lane;
-      slot[j] = (j * kWave < n && e < n) ? a.pool[r * (int64_t)S2 + e] : -1;
+      slot[j] = (j * kWave < n && e < n) ? a.pool[r * (int64_t)kTilesBase + e] : -1;   // n <= NBR * 64 = kTilesBase
     }
 #pragma unroll
     for (int j = 0; j < NBR; ++j) {
@@ -186,7 +195,7 @@ __device__ void select_query(const KnnTilesArgs& a, int64_t r, const QRec& rec, 
     if (n > SL / 2) {
       double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
       for (int e = lane; e < n; e += kWave) {
-        const int slot = a.pool[r * (int64_t)S2 + e];
+        const int slot = pool_read(a, r, e);
         const double dx = qx - a.tx[slot], dy = qy - a.ty[slot], dz = qz - a.tz[slot];
         const double d = (dx * dx + dy * dy) + dz * dz;
         m2 = d < m1 ? m1 : (d < m2 ? d : m2);
@@ -205,7 +214,7 @@ __device__ void select_query(const KnnTilesArgs& a, int64_t r, const QRec& rec, 
       double d = 0.0;
       int orig = 0;
       if (e < n) {
-        const int slot = a.pool[r * (int64_t)S2 + e];
+        const int slot = pool_read(a, r, e);
         orig = a.torig[slot];
         const double dx = qx - a.tx[slot], dy = qy - a.ty[slot], dz = qz - a.tz[slot];
         d = (dx * dx + dy * dy) + dz * dz;  // knn_cpu.cpp:43-50 order, unfused
@@ -271,12 +280,12 @@ __device__ void select_query(const KnnTilesArgs& a, int64_t r, const QRec& rec, 
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
+__global__ __launch_bounds__(256, 2) void k_knn_seed(KnnTilesArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int K = a.K, S2 = a.S2, n_tiles = a.n_tiles;
-  constexpr size_t kScratch = 10240;  // >= QB*64*8 + 512 + 1024 (seed), QCAP*8 (queue), S2*12 (select, S2 <= 768)
+  const int K = a.K, n_tiles = a.n_tiles;
+  constexpr size_t kScratch = 10240;  // >= QB*64*8 + 512 + 1024 (seed buffers)
   constexpr size_t per_wave = sizeof(QD) * QW + sizeof(QF) * QW + 4 * sizeof(int) * QW + kScratch;
   unsigned char* base = smem + per_wave * wave;
   QD* qd = reinterpret_cast<QD*>(base);
@@ -289,9 +298,6 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
   float2* lm = reinterpret_cast<float2*>(scratch);                 // seed: [QB][64] two minima
   float* sv = reinterpret_cast<float*>(scratch + sizeof(float2) * QB * kWave);  // seed: [128] sort buffer
   unsigned int* tbits = reinterpret_cast<unsigned int*>(sv + 128);              // seed: tile bitmap [MAX_TILES/32]
-  int2* queue = reinterpret_cast<int2*>(scratch);                  // scan: [QCAP] {slot, q}
-  double* sd = reinterpret_cast<double*>(scratch);                 // select: [SL]
-  int* si = reinterpret_cast<int*>(scratch + sizeof(double) * (size_t)SL);
 
   const int64_t q0blk = a.b_lo + (int64_t)blockIdx.x * WAVES * QW;  // first query position of the workgroup
   const int64_t q0 = q0blk + (int64_t)wave * QW;
@@ -426,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
         while (bits) {
           const int tile = (wd << 5) + (int)__builtin_ctz(bits);
           bits &= bits - 1;
+          if (a.phase_cycles) pacc[4] += 1;
           const int64_t tb = (int64_t)tile * STEP;
           float x[T], y[T], z[T];
 #pragma unroll
@@ -457,156 +464,227 @@ __global__ __launch_bounds__(256, 2) void k_knn_tiles(KnnTilesArgs a) {
           const int c = __popcll(__ballot(kx <= t_try)) + __popcll(__ballot(ky <= t_try));
           if (c < K) kth |= 1u << bit;
         }
-        if (lane == 0) {
-          const double tv = (double)__uint_as_float(kth);  // K <= 128 witnesses with f32 distance <= tv
-          const int qq = qb0 + q;
-          const double E = fmax(Et, fmax(fabs(qd[qq].x), fmax(fabs(qd[qq].y), fabs(qd[qq].z))));
-          double tau = __builtin_huge_val();
-          if (tv < (double)__builtin_huge_valf()) {
-            const double r = sqrt(tv) * (1.0 + 1e-6) + 4.0 * kU * E;  // exact distance of every witness <= r
-            tau = (r * r) * (1.0 + 1e-12);
-          }
-          qd[qq].tau = tau;
-          const float thr = filter_threshold(tau, E);
-          qf[qq].thr = thr;
-          float tb = __builtin_huge_valf();
-          if (thr < __builtin_huge_valf()) {  // point-to-box test uses the rounded query: allow its rounding error
-            const double rb = sqrt((double)thr) + 2.0 * kU * E;
-            tb = f32_round_up((rb * rb) * (1.0 + 1e-6));
-          }
-          thrb[qq] = tb;
-        }
-        wave_sync();
+        if (lane == 0) spare[qb0 + q] = (int)kth;  // K <= 128 witnesses with f32 distance <= this value
       }
+      wave_sync();
     }
+    if (lane < nq) {  // thresholds of all queries at once, one lane per query
+      const double tv = (double)__uint_as_float((unsigned int)spare[lane]);
+      const double E = fmax(Et, fmax(fabs(qd[lane].x), fmax(fabs(qd[lane].y), fabs(qd[lane].z))));
+      double tau = __builtin_huge_val();
+      if (tv < (double)__builtin_huge_valf()) {
+        const double r = sqrt(tv) * (1.0 + 1e-6) + 4.0 * kU * E;  // exact distance of every witness <= r
+        tau = (r * r) * (1.0 + 1e-12);
+      }
+      qd[lane].tau = tau;
+      const float thr = filter_threshold(tau, E);
+      qf[lane].thr = thr;
+      float tb = __builtin_huge_valf();
+      if (thr < __builtin_huge_valf()) {  // point-to-box test uses the rounded query: allow its rounding error
+        const double rb = sqrt((double)thr) + 2.0 * kU * E;
+        tb = f32_round_up((rb * rb) * (1.0 + 1e-6));
+      }
+      thrb[lane] = tb;
+    }
+    wave_sync();
   }
 
   phase_mark(1);
-  // ---- 2. scan the tiles that can matter — shared by the workgroup ----
-  // Each wave takes every fourth tile and scores it for the queries of ALL four waves (their records stay in the
-  // owners' LDS regions).  One wave's queries can need several times the median work (loose thresholds); spread
-  // over four waves the slowest workgroup, which sets the kernel time, is much closer to the average.
-  __shared__ float s_gbox[WAVES][8];  // per wave: query box lo xyz, hi xyz, largest box-test threshold, query count
-  {
-    float tmax = thrb[lane];  // -1 for inactive lanes
-    for (int off = 32; off > 0; off >>= 1) tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, off, kWave));
-    if (lane == 0) {
-      s_gbox[wave][0] = wlo0; s_gbox[wave][1] = wlo1; s_gbox[wave][2] = wlo2;
-      s_gbox[wave][3] = whi0; s_gbox[wave][4] = whi1; s_gbox[wave][5] = whi2;
-      s_gbox[wave][6] = nq > 0 ? tmax : -1.0f; s_gbox[wave][7] = __int_as_float(nq);
-    }
-  }
-  __syncthreads();
-  auto grp_qf = [&](int g) { return reinterpret_cast<QF*>(smem + per_wave * g + sizeof(QD) * QW); };
-  auto grp_cnt = [&](int g) { return reinterpret_cast<int*>(smem + per_wave * g + (sizeof(QD) + sizeof(QF)) * QW); };
-  auto grp_thrb = [&](int g) { return reinterpret_cast<float*>(smem + per_wave * g + (sizeof(QD) + sizeof(QF)) * QW + 2 * sizeof(int) * QW); };
-  int qcount = 0;
-  auto flush = [&]() {
-    wave_sync();
-    for (int e = lane; e < qcount; e += kWave) {
-      const int2 ent = queue[e];
-      const int g = ent.y >> 6, q = ent.y & (QW - 1);
-      const int pos = atomicAdd(&grp_cnt(g)[q], 1);
-      if (pos < S2) a.pool[(q0blk + (int64_t)g * QW + q) * (int64_t)S2 + pos] = ent.x;
-    }
-    qcount = 0;
-    wave_sync();
-  };
-  {
-    float gx[WAVES], gy[WAVES], gz[WAVES], gtb[WAVES];  // lane's query of each group, and its box-test threshold
-    int gnq[WAVES];
-#pragma unroll
-    for (int g = 0; g < WAVES; ++g) {
-      const QF f = grp_qf(g)[lane];
-      gx[g] = f.x; gy[g] = f.y; gz[g] = f.z; gtb[g] = grp_thrb(g)[lane];
-      gnq[g] = __float_as_int(s_gbox[g][7]);
-    }
-    const unsigned long long own = 0x1111111111111111ull << wave;  // tiles t with t % 4 == wave (t0 is a multiple of 64)
-    for (int t0 = 0; t0 < n_tiles; t0 += kWave) {
-      const int tl = t0 + lane;
-      unsigned long long gmask[WAVES];
-      unsigned long long any = 0ull;
-#pragma unroll
-      for (int g = 0; g < WAVES; ++g) {
-        bool need = false;
-        if (tl < n_tiles)
-          need = box_lb2(s_gbox[g][0], s_gbox[g][1], s_gbox[g][2], s_gbox[g][3], s_gbox[g][4], s_gbox[g][5], bx_lo0[tl], bx_lo1[tl],
-                         bx_lo2[tl], bx_hi0[tl], bx_hi1[tl], bx_hi2[tl]) <= s_gbox[g][6];
-        gmask[g] = __ballot(need) & own;
-        any |= gmask[g];
-      }
-      while (any) {
-        const int bit = (int)__builtin_ctzll(any);
-        any &= any - 1;
-        const int tile = t0 + bit;
-        const float l0 = bx_lo0[tile], l1 = bx_lo1[tile], l2 = bx_lo2[tile], h0 = bx_hi0[tile], h1 = bx_hi1[tile], h2 = bx_hi2[tile];
-        const int64_t tb = (int64_t)tile * STEP;
-        float x[T], y[T], z[T];
-        bool loaded = false;
-#pragma unroll
-        for (int g = 0; g < WAVES; ++g) {
-          if (!((gmask[g] >> bit) & 1ull)) continue;  // wave-uniform
-          unsigned long long qmask = __ballot(lane < gnq[g] && box_lb2(gx[g], gy[g], gz[g], gx[g], gy[g], gz[g], l0, l1, l2, h0, h1, h2) <= gtb[g]);
-          if (!qmask) continue;
-          if (!loaded) {
-#pragma unroll
-            for (int t = 0; t < T; ++t) { x[t] = a.txf[tb + t * kWave + lane]; y[t] = a.tyf[tb + t * kWave + lane]; z[t] = a.tzf[tb + t * kWave + lane]; }
-            loaded = true;
-          }
-          const QF* gqf = grp_qf(g);
-          while (qmask) {
-            const int q = (int)__builtin_ctzll(qmask);
-            qmask &= qmask - 1;
-            const float4 cur = *reinterpret_cast<const float4*>(&gqf[q]);
-            float d[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-              const float dx = cur.x - x[t], dy = cur.y - y[t], dz = cur.z - z[t];
-              d[t] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            }
-            float dm = __builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]);
-#pragma unroll
-            for (int t = 3; t + 1 < T; t += 2) dm = __builtin_fminf(__builtin_fminf(dm, d[t]), d[t + 1]);
-            if constexpr ((T - 3) % 2 == 1) dm = __builtin_fminf(dm, d[T - 1]);
-            if (__ballot(dm <= cur.w)) {
-#pragma unroll
-              for (int t = 0; t < T; ++t) {
-                const unsigned long long m = __ballot(d[t] <= cur.w);
-                if (m) {
-                  const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                  if ((m >> lane) & 1ull) queue[pos] = make_int2((int)(tb + t * kWave + lane), g * 64 + q);
-                  qcount += __popcll(m);
-                }
-              }
-              qcount = __builtin_amdgcn_readfirstlane(qcount);
-              if (qcount > QCAP - STEP) flush();
-            }
-          }
-        }
-      }
-    }
-    flush();
-  }
-  __syncthreads();  // every wave's survivors are counted before the owners publish their records
-
-  phase_mark(2);
-  // ---- 3. hand over: the select phase runs as its own kernel (one wave per query, all CUs, balanced) ----
+  // ---- 2. hand over: thresholds and positions go to the scan kernel (its own launch: one workgroup per 64 queries, so a
+  // heavy group no longer pins the three lighter groups of its workgroup, and the hardware balances the groups) ----
   if (lane < nq) {
     QRec rec;
     rec.x = qd[lane].x; rec.y = qd[lane].y; rec.z = qd[lane].z; rec.tau = qd[lane].tau;
-    rec.cnt = cnt[lane]; rec.row = qb[lane]; rec.pad0 = 0; rec.pad1 = 0;
+    rec.cnt = 0; rec.row = qb[lane]; rec.thr = qf[lane].thr; rec.tb = thrb[lane];
     reinterpret_cast<QRec*>(a.qrec)[q0 + lane] = rec;
   }
   phase_mark(3);
   if (a.phase_cycles && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&a.phase_cycles[i], pacc[i]);
+    for (int i = 0; i < 5; ++i) atomicAdd(&a.phase_cycles[i], pacc[i]);
     unsigned long long* pw = a.phase_cycles + 8 + 8 * ((size_t)blockIdx.x * WAVES + wave);  // per-wave record
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pw[i] = pacc[i];
-    int nsum = 0;
-    for (int q = 0; q < nq; ++q) nsum += cnt[q];
-    pw[7] = (unsigned long long)nsum;  // survivors of this wave's queries
+    for (int i = 0; i < 5; ++i) pw[i] = pacc[i];
+  }
+}
+
+// ---- scan: the tiles that can matter for one group of 64 consecutive (Morton-ordered) queries ----
+// Tiles whose box is farther from the group's box than the group's largest threshold are skipped (one vector test per
+// 64 tiles).  The remaining tiles are drawn, one at a time, from the workgroup's ticket counter by its SW waves (a fixed
+// split left waves idle at the final barrier for 23 % of the wave cycles; counters in global memory, tried so that several
+// workgroups could share a group, cost more than they balanced).  Inside a tile, queries whose point-to-box bound exceeds
+// their own threshold are skipped (one vector test per tile); the rest run the f32 pre-filter and the survivors go to the
+// query's pool.
+template <int SW>
+__global__ __launch_bounds__(64 * SW) void k_knn_scan_tiles(KnnTilesArgs a) {
+  __shared__ __align__(16) QF s_qf[QW];
+  __shared__ int s_cnt[QW];
+  __shared__ int s_ticket;
+  __shared__ __align__(16) int2 s_queue[SW][QCAP];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int S2 = a.S2, n_tiles = a.n_tiles;
+  int2* queue = s_queue[wave];
+  const int64_t q0 = a.b_lo + (int64_t)blockIdx.x * QW;
+  const int nq = (a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW;
+  QRec* recs = reinterpret_cast<QRec*>(a.qrec);
+  unsigned long long tphase = a.phase_cycles ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto phase_mark = [&](int i) {
+    if (!a.phase_cycles) return;
+    const unsigned long long now = __builtin_readcyclecounter();
+    pacc[i] += now - tphase;
+    tphase = now;
+  };
+  // every wave keeps the group's queries in registers (lane = query) for the box tests; the pair loop reads them from LDS
+  float gx = 0.f, gy = 0.f, gz = 0.f, gtb = -1.0f;
+  float wlo0, wlo1, wlo2, whi0, whi1, whi2, tmax;
+  {
+    const bool act = lane < nq;
+    QF f; f.x = f.y = f.z = 0.f; f.thr = -1.0f;
+    const float inf = __builtin_huge_valf();
+    wlo0 = wlo1 = wlo2 = inf; whi0 = whi1 = whi2 = -inf;
+    if (act) {
+      const QRec rec = recs[q0 + lane];
+      f.x = (float)rec.x; f.y = (float)rec.y; f.z = (float)rec.z; f.thr = rec.thr;
+      gtb = rec.tb;
+      wlo0 = f32_floor(rec.x); wlo1 = f32_floor(rec.y); wlo2 = f32_floor(rec.z);
+      whi0 = f32_ceil(rec.x); whi1 = f32_ceil(rec.y); whi2 = f32_ceil(rec.z);
+    }
+    gx = f.x; gy = f.y; gz = f.z;
+    if (wave == 0) { s_qf[lane] = f; s_cnt[lane] = 0; }
+    if (threadIdx.x == 0) s_ticket = 0;
+    tmax = gtb;
+    for (int off = 32; off > 0; off >>= 1) {
+      wlo0 = __builtin_fminf(wlo0, __shfl_xor(wlo0, off, kWave)); whi0 = __builtin_fmaxf(whi0, __shfl_xor(whi0, off, kWave));
+      wlo1 = __builtin_fminf(wlo1, __shfl_xor(wlo1, off, kWave)); whi1 = __builtin_fmaxf(whi1, __shfl_xor(whi1, off, kWave));
+      wlo2 = __builtin_fminf(wlo2, __shfl_xor(wlo2, off, kWave)); whi2 = __builtin_fmaxf(whi2, __shfl_xor(whi2, off, kWave));
+      tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, off, kWave));
+    }
+  }
+  __syncthreads();
+  const float* bx_lo0 = a.tile_box, *bx_lo1 = a.tile_box + n_tiles, *bx_lo2 = a.tile_box + 2 * (size_t)n_tiles;
+  const float* bx_hi0 = a.tile_box + 3 * (size_t)n_tiles, *bx_hi1 = a.tile_box + 4 * (size_t)n_tiles,
+             * bx_hi2 = a.tile_box + 5 * (size_t)n_tiles;
+  // Survivors are queued per wave and drained 64 at a time: entries of one (query, tile row) are adjacent, and each run
+  // of equal queries reserves its pool positions with one update of the query's counter (LDS) by its first lane.
+  // Positions past the query's own pool row live in arena chunks: the lane that gets the first position of a chunk
+  // allocates it and publishes its id in chunk_tab, the others (in this wave or another wave of the workgroup — never in
+  // another workgroup: a query's counter is workgroup-local) wait for the id.  The allocating lane has finished its store
+  // before any lane of its own wave starts to wait, and other waves do not hold it up, so the wait ends; it is bounded
+  // anyway, and a query whose chunk could not be had (arena exhausted) is marked failed and redone exactly by the fallback.
+  int qcount = 0;
+  auto put = [&](int q, int pos, bool on, int slot) {
+    const int64_t r = q0 + q;
+    if (on && pos < kTilesBase) a.pool[r * kTilesBase + pos] = slot;
+    const bool ovf = on && pos >= kTilesBase && pos < S2;
+    if (__ballot(ovf)) {
+      const int o = pos - kTilesBase;
+      int32_t* tab = a.chunk_tab + r * kTilesChunks + (ovf ? o / kTilesChunk : 0);
+      if (ovf && (o % kTilesChunk) == 0) {
+        int id = atomicAdd(a.chunk_tab + a.tab_rows * (int64_t)kTilesChunks, 1) + 1;
+        if (id >= a.arena_cap) id = -2;
+        __hip_atomic_store(tab, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (ovf) {
+        int id = -1;
+        for (int spin = 0; spin < (1 << 22) && id == -1; ++spin) {
+          id = __hip_atomic_load(tab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (id == -1) __builtin_amdgcn_s_sleep(2);
+        }
+        if (id >= 0) a.arena[(int64_t)id * kTilesChunk + (o % kTilesChunk)] = slot;
+        else atomicMax(&s_cnt[q], 1 << 24);  // no chunk: more than S2 survivors on record -> the select phase hands the query to the fallback
+      }
+    }
+  };
+  auto flush = [&]() {
+    wave_sync();
+    for (int e0 = 0; e0 < qcount; e0 += kWave) {
+      const int e = e0 + lane;
+      const bool on = e < qcount;
+      const int2 ent = on ? queue[e] : make_int2(0, -1 - lane);
+      const int prev = __shfl_up(ent.y, 1, kWave);
+      const unsigned long long lead = __ballot(on && (lane == 0 || ent.y != prev));
+      const unsigned long long upto = lead & (~0ull >> (63 - lane));               // leaders at or below this lane
+      const int L = 63 - (int)__builtin_clzll(upto | 1ull);
+      const unsigned long long after = lead & ~((2ull << L) - 1ull);
+      const int nvalid = (qcount - e0) < kWave ? (qcount - e0) : kWave;
+      const int end = after ? (int)__builtin_ctzll(after) : nvalid;
+      const int q = ent.y & (QW - 1);
+      int base = 0;
+      if (on && lane == L) base = atomicAdd(&s_cnt[q], end - L);
+      base = __shfl(base, L, kWave);
+      put(q, base + (lane - L), on, ent.x);
+    }
+    qcount = 0;
+    wave_sync();
+  };
+  {
+    auto next_ticket = [&]() { int v = 0; if (lane == 0) v = atomicAdd(&s_ticket, 1); return __builtin_amdgcn_readfirstlane(v); };
+    int my = next_ticket(), seen = 0;
+    for (int t0 = 0; t0 < n_tiles; t0 += kWave) {
+      const int tl = t0 + lane;
+      bool need = false;
+      if (tl < n_tiles)
+        need = box_lb2(wlo0, wlo1, wlo2, whi0, whi1, whi2, bx_lo0[tl], bx_lo1[tl], bx_lo2[tl], bx_hi0[tl], bx_hi1[tl], bx_hi2[tl]) <= tmax;
+      const unsigned long long any = __ballot(need);
+      const int n_here = __popcll(any);
+      while (my < seen + n_here) {
+        unsigned long long rem = any;
+        for (int k = my - seen; k > 0; --k) rem &= rem - 1;
+        const int tile = t0 + (int)__builtin_ctzll(rem);
+        my = next_ticket();   // drawn early: the counter's latency hides behind this tile's work
+        if (a.phase_cycles) pacc[5] += 1;
+        const float l0 = bx_lo0[tile], l1 = bx_lo1[tile], l2 = bx_lo2[tile], h0 = bx_hi0[tile], h1 = bx_hi1[tile], h2 = bx_hi2[tile];
+        unsigned long long qmask = __ballot(lane < nq && box_lb2(gx, gy, gz, gx, gy, gz, l0, l1, l2, h0, h1, h2) <= gtb);
+        if (!qmask) continue;
+        if (a.phase_cycles) pacc[6] += __popcll(qmask);
+        const int64_t tb = (int64_t)tile * STEP;
+        float x[T], y[T], z[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) { x[t] = a.txf[tb + t * kWave + lane]; y[t] = a.tyf[tb + t * kWave + lane]; z[t] = a.tzf[tb + t * kWave + lane]; }
+        while (qmask) {
+          const int q = (int)__builtin_ctzll(qmask);
+          qmask &= qmask - 1;
+          const float4 cur = *reinterpret_cast<const float4*>(&s_qf[q]);
+          float d[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const float dx = cur.x - x[t], dy = cur.y - y[t], dz = cur.z - z[t];
+            d[t] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          }
+          float dm = __builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]);
+#pragma unroll
+          for (int t = 3; t + 1 < T; t += 2) dm = __builtin_fminf(__builtin_fminf(dm, d[t]), d[t + 1]);
+          if constexpr ((T - 3) % 2 == 1) dm = __builtin_fminf(dm, d[T - 1]);
+          if (__ballot(dm <= cur.w)) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const bool hit = d[t] <= cur.w;
+              const unsigned long long m = __ballot(hit);
+              if (m) {
+                const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                if (hit) queue[pos] = make_int2((int)(tb + t * kWave + lane), q);
+                qcount += __popcll(m);
+              }
+            }
+            qcount = __builtin_amdgcn_readfirstlane(qcount);
+            if (qcount > QCAP - STEP) flush();
+          }
+        }
+      }
+      seen += n_here;
+    }
+    flush();
+  }
+  phase_mark(2);
+  __syncthreads();  // every wave's survivors are counted before the counts are published
+  phase_mark(3);
+  if (wave == 0 && lane < nq) recs[q0 + lane].cnt = s_cnt[lane];
+  if (a.phase_cycles && lane == 0) {
+    atomicAdd(&a.phase_cycles[2], pacc[2]); atomicAdd(&a.phase_cycles[3], pacc[3]);
+    atomicAdd(&a.phase_cycles[5], pacc[5]); atomicAdd(&a.phase_cycles[6], pacc[6]);
+    atomicMax(&a.phase_cycles[7], pacc[2]);   // slowest scan wave
   }
 }
 
@@ -634,10 +712,14 @@ hipError_t launch_knn_tiles(const KnnTilesArgs& a, hipStream_t st) {
   const size_t per_wave = sizeof(QD) * QW + sizeof(QF) * QW + 4 * sizeof(int) * QW + 10240;
   if (a.n_tiles > MAX_TILES) return hipErrorInvalidValue;
   const size_t smem = per_wave * WAVES;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_tiles),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_seed),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_knn_tiles, dim3((unsigned)nb), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(k_knn_seed, dim3((unsigned)nb), dim3(256), smem, st, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (a.scan_split == 4) hipLaunchKernelGGL(k_knn_scan_tiles<4>, dim3((unsigned)((nq + QW - 1) / QW)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_knn_scan_tiles<8>, dim3((unsigned)((nq + QW - 1) / QW)), dim3(512), 0, st, a);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   int64_t nbs = (nq + WAVES - 1) / WAVES;

@@ -89,7 +89,7 @@ struct KnnTilesArgs {
   void* qrec;         // [B] 48-byte per-query records (position, threshold, survivor count) between the two kernels
   double* fail_tau;   // optional [B]: a valid threshold (>= K-th distance) of each failed query, +inf if none
 };
-constexpr int kTilesBase = 512, kTilesChunk = 512, kTilesChunks = 15;   // 512 + 15 * 512 = 8192 survivors per query at most
+constexpr int kTilesBase = 512, kTilesChunk = 512, kTilesChunks = 31;   // 512 + 31 * 512 = 16384 survivors per query at most
 bool knn_tiles_applicable(int64_t Mp, int K);
 hipError_t launch_knn_tiles(const KnnTilesArgs& a, hipStream_t st);
 size_t sort_temp_bytes(size_t n);

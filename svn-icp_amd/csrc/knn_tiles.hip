@@ -245,20 +245,27 @@ __device__ void select_query(const KnnTilesArgs& a, int64_t r, const QRec& rec, 
     const int e0 = lane, e1 = lane + kWave;
     const double d0 = e0 < m ? sd[e0] : 0.0, d1 = e1 < m ? sd[e1] : 0.0;
     const int i0 = e0 < m ? si[e0] : 0, i1 = e1 < m ? si[e1] : 0;
-    // rank = #(d_j < d) + #(d_j == d and i_j < i): the first count is compare + add-with-carry per entry (no
-    // scalar mask logic, which is slow behind vector compares on this chip); the second only when ties exist
-    int r0 = 0, r1 = 0, q0c = 0, q1c = 0;
+    // rank = #(d_j < d) + #(d_j == d and i_j < i).  The first count is compare + add-with-carry per entry (no scalar
+    // mask logic, which is slow behind vector compares on this chip).  Exact ties are rare: they show up as two entries
+    // with the same first count (a flag per rank in LDS), and only then does the second count run.
+    int* flag = si + 2 * kWave + 8;   // [128] behind the entries
+    flag[lane] = 0; flag[lane + kWave] = 0;
+    int r0 = 0, r1 = 0;
     for (int j0 = 0; j0 < m; j0 += 8) {  // eight broadcast reads in flight; entries past m are +inf (never less)
       double dj[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) dj[u] = sd[j0 + u];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        r0 += dj[u] < d0 ? 1 : 0; q0c += dj[u] == d0 ? 1 : 0;
-        r1 += dj[u] < d1 ? 1 : 0; q1c += dj[u] == d1 ? 1 : 0;
+        r0 += dj[u] < d0 ? 1 : 0;
+        r1 += dj[u] < d1 ? 1 : 0;
       }
     }
-    if (__ballot((e0 < m && q0c > 1) || (e1 < m && q1c > 1))) {  // exact ties: order them by original index
+    wave_sync();
+    if (e0 < m) atomicAdd(&flag[r0], 1);
+    if (e1 < m) atomicAdd(&flag[r1], 1);
+    wave_sync();
+    if (__ballot((e0 < m && flag[r0] > 1) || (e1 < m && flag[r1] > 1))) {  // exact ties: order them by original index
       for (int j = 0; j < m; ++j) {
         const double dj = sd[j];
         const int ij = si[j];
@@ -280,29 +287,30 @@ __device__ void select_query(const KnnTilesArgs& a, int64_t r, const QRec& rec, 
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k_knn_seed(KnnTilesArgs a) {
+__global__ __launch_bounds__(256) void k_knn_seed(KnnTilesArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int K = a.K, n_tiles = a.n_tiles;
-  constexpr size_t kScratch = 10240;  // >= QB*64*8 + 512 + 1024 (seed buffers)
-  constexpr size_t per_wave = sizeof(QD) * QW + sizeof(QF) * QW + 4 * sizeof(int) * QW + kScratch;
-  unsigned char* base = smem + per_wave * wave;
-  QD* qd = reinterpret_cast<QD*>(base);
-  QF* qf = reinterpret_cast<QF*>(base + sizeof(QD) * QW);
-  int* cnt = reinterpret_cast<int*>(base + (sizeof(QD) + sizeof(QF)) * QW);
+  // one workgroup = one group of 64 queries: wave 0 loads and ranks (lane = query), then each of the four waves seeds one
+  // batch of QB = 16 queries against the tiles the group picked, then wave 0 turns the K-th values into thresholds.
+  // (One wave per group did all four batches in sequence: 2048 long-running waves at C3, two per SIMD, the slowest 1.6x
+  // the median, set the kernel time.)
+  constexpr size_t kShared = sizeof(QD) * QW + sizeof(QF) * QW + 4 * sizeof(int) * QW + sizeof(unsigned int) * (MAX_TILES / 32);
+  constexpr size_t kScratch = sizeof(float2) * QB * kWave + 512;   // per wave: two minima per (query of the batch, lane); rank: 64 boxes
+  static_assert(QB * WAVES == QW, "one batch per wave");
+  QD* qd = reinterpret_cast<QD*>(smem);
+  QF* qf = reinterpret_cast<QF*>(smem + sizeof(QD) * QW);
+  int* cnt = reinterpret_cast<int*>(smem + (sizeof(QD) + sizeof(QF)) * QW);
   int* qb = cnt + QW;                                   // original row of each query
   float* thrb = reinterpret_cast<float*>(qb + QW);      // box-test threshold per query
-  int* spare = reinterpret_cast<int*>(thrb + QW);       // [QW] unused padding
-  unsigned char* scratch = reinterpret_cast<unsigned char*>(spare + QW);
+  int* spare = reinterpret_cast<int*>(thrb + QW);       // K-th value of each query (float bits)
+  unsigned int* tbits = reinterpret_cast<unsigned int*>(spare + QW);   // tile bitmap [MAX_TILES/32]
+  unsigned char* scratch = smem + kShared + kScratch * wave;
   float2* lm = reinterpret_cast<float2*>(scratch);                 // seed: [QB][64] two minima
-  float* sv = reinterpret_cast<float*>(scratch + sizeof(float2) * QB * kWave);  // seed: [128] sort buffer
-  unsigned int* tbits = reinterpret_cast<unsigned int*>(sv + 128);              // seed: tile bitmap [MAX_TILES/32]
 
-  const int64_t q0blk = a.b_lo + (int64_t)blockIdx.x * WAVES * QW;  // first query position of the workgroup
-  const int64_t q0 = q0blk + (int64_t)wave * QW;
-  // a wave past the end keeps running with no queries: the scan phase below is shared by the workgroup's waves
-  const int nq = q0 >= a.b_hi ? 0 : ((a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW);
+  const int64_t q0 = a.b_lo + (int64_t)blockIdx.x * QW;  // first query position of the workgroup
+  const int nq = (a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW;
   const double Et = __longlong_as_double((long long)*a.emax_bits);
 
   unsigned long long tphase = a.phase_cycles ? __builtin_readcyclecounter() : 0ull;
@@ -313,9 +321,10 @@ __global__ __launch_bounds__(256, 2) void k_knn_seed(KnnTilesArgs a) {
     pacc[i] += now - tphase;
     tphase = now;
   };
-  // ---- 0. this wave's queries (curve order) and their common box ----
-  float wlo0, wlo1, wlo2, whi0, whi1, whi2;
-  {
+  // ---- 0. the group's queries (curve order) and their common box ----
+  float wlo0 = 0.f, wlo1 = 0.f, wlo2 = 0.f, whi0 = 0.f, whi1 = 0.f, whi2 = 0.f;
+  const int nwords = (n_tiles + 31) >> 5;
+  if (wave == 0) {
     const bool act = lane < nq;
     const int64_t b = act ? (int64_t)a.qorder[q0 - a.b_lo + lane] : 0;
     QD s; s.x = s.y = s.z = 0.0; s.tau = 0.0;
@@ -347,11 +356,10 @@ __global__ __launch_bounds__(256, 2) void k_knn_seed(KnnTilesArgs a) {
   // ---- 1. seed: nearest tiles, two minima per (query, lane), K-th of 128 -> guaranteed threshold ----
   {
     // each query (lane) picks its own NSQ nearest tiles: point-to-box bound, ties (inside several
-    // boxes) broken toward the nearest box centre; the wave scans the union of all picks
-    const int nwords = (n_tiles + 31) >> 5;
-    for (int e = lane; e < nwords; e += kWave) tbits[e] = 0u;
-    wave_sync();
-    {
+    // boxes) broken toward the nearest box centre; the workgroup scans the union of all picks
+    if (wave == 0) {
+      for (int e = lane; e < nwords; e += kWave) tbits[e] = 0u;
+      wave_sync();
       const float px = qf[lane].x, py = qf[lane].y, pz = qf[lane].z;
       unsigned long long best[NSQ];
 #pragma unroll
@@ -421,9 +429,11 @@ __global__ __launch_bounds__(256, 2) void k_knn_seed(KnnTilesArgs a) {
           if (best[i] != ~0ull) { const unsigned int t = (unsigned int)(best[i] & 0xffffffffull); atomicOr(&tbits[t >> 5], 1u << (t & 31)); }
       }
     }
-    wave_sync();
     phase_mark(0);
-    for (int qb0 = 0; qb0 < nq; qb0 += QB) {
+    __syncthreads();
+    phase_mark(3);
+    const int qb0 = wave * QB;   // this wave's batch
+    if (qb0 < nq) {
       const int nb = (nq - qb0) < QB ? (nq - qb0) : QB;
       for (int e = lane; e < QB * kWave; e += kWave) lm[e] = make_float2(__builtin_huge_valf(), __builtin_huge_valf());
       wave_sync();
@@ -466,9 +476,11 @@ __global__ __launch_bounds__(256, 2) void k_knn_seed(KnnTilesArgs a) {
         }
         if (lane == 0) spare[qb0 + q] = (int)kth;  // K <= 128 witnesses with f32 distance <= this value
       }
-      wave_sync();
     }
-    if (lane < nq) {  // thresholds of all queries at once, one lane per query
+    phase_mark(1);
+    __syncthreads();
+    phase_mark(3);
+    if (wave == 0 && lane < nq) {  // thresholds of all queries at once, one lane per query
       const double tv = (double)__uint_as_float((unsigned int)spare[lane]);
       const double E = fmax(Et, fmax(fabs(qd[lane].x), fmax(fabs(qd[lane].y), fabs(qd[lane].z))));
       double tau = __builtin_huge_val();
@@ -489,16 +501,15 @@ __global__ __launch_bounds__(256, 2) void k_knn_seed(KnnTilesArgs a) {
     wave_sync();
   }
 
-  phase_mark(1);
   // ---- 2. hand over: thresholds and positions go to the scan kernel (its own launch: one workgroup per 64 queries, so a
   // heavy group no longer pins the three lighter groups of its workgroup, and the hardware balances the groups) ----
-  if (lane < nq) {
+  if (wave == 0 && lane < nq) {
     QRec rec;
     rec.x = qd[lane].x; rec.y = qd[lane].y; rec.z = qd[lane].z; rec.tau = qd[lane].tau;
     rec.cnt = 0; rec.row = qb[lane]; rec.thr = qf[lane].thr; rec.tb = thrb[lane];
     reinterpret_cast<QRec*>(a.qrec)[q0 + lane] = rec;
   }
-  phase_mark(3);
+  phase_mark(1);
   if (a.phase_cycles && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) atomicAdd(&a.phase_cycles[i], pacc[i]);
@@ -708,10 +719,10 @@ bool knn_tiles_applicable(int64_t Mp, int K) { return K <= 128 && Mp >= 16 * STE
 hipError_t launch_knn_tiles(const KnnTilesArgs& a, hipStream_t st) {
   const int64_t nq = a.b_hi - a.b_lo;
   if (nq <= 0) return hipSuccess;
-  const int64_t nb = (nq + (int64_t)QW * WAVES - 1) / ((int64_t)QW * WAVES);
-  const size_t per_wave = sizeof(QD) * QW + sizeof(QF) * QW + 4 * sizeof(int) * QW + 10240;
+  const int64_t nb = (nq + QW - 1) / QW;
   if (a.n_tiles > MAX_TILES) return hipErrorInvalidValue;
-  const size_t smem = per_wave * WAVES;
+  const size_t smem = sizeof(QD) * QW + sizeof(QF) * QW + 4 * sizeof(int) * QW + sizeof(unsigned int) * (MAX_TILES / 32) +
+                      (sizeof(float2) * QB * kWave + 512) * WAVES;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_seed),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;

@@ -701,8 +701,9 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
   }
 }
 
-// Front half of the Stein step for 2 <= P <= 128 in ONE workgroup (the pair work is small, a launch is not):
-// per-particle H, b, Newton step and x (as k_upd_prepare), mean Hessian inverse, and the exact lower median of
+// Front half of the Stein step for 2 <= P <= 128 in one launch of a few workgroups that do not wait for each other
+// (the pair work is small, a launch is not): workgroup 0 the exact lower median, workgroup 1 the mean Hessian inverse,
+// workgroups 2.. per-particle H, b, Newton step (as k_upd_prepare).  The median: the exact lower median of
 // the P² pair distances through an LDS copy of the log-binned histogram of the k_upd_* chain: bin the keys,
 // find the median's bin, collect that bin (~0.4 % of the keys), rank its keys by counting.  k_upd_direction
 // (one wavefront per particle, pose update fused) then runs on as many CUs as there are particles.
@@ -759,21 +760,29 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
     }
     return;
   }
+  if (blockIdx.x >= 2) {
+    // workgroups 2..: H, b and the Newton step of 64 particles each (SVNICP.cpp:146-162) — a 6x6 LU per thread, a long
+    // serial chain that only k_upd_direction needs; it used to run ahead of the median on workgroup 0 (a third of its time)
+    const int p = (blockIdx.x - 2) * 64 + tid;
+    if (tid < 64 && p < P) {
+      double Rc[9], H[36], b[6], LU[36], x6[6];
+      int piv[6];
+      mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
+      finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; }
+      const bool ok = lu6(LU, piv);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) x6[i] = b[i];
+      lu6_solve(LU, piv, x6);                                   // SVNICP.cpp:162
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { w.b[p * 6 + i] = b[i]; w.N[p * 6 + i] = ok ? x6[i] : __builtin_nan(""); }
+    }
+    return;
+  }
   for (int e = tid; e < HB_NB; e += UT) lh[e] = 0u;
   if (tid == 0) { sh_cnt = 0u; sh_nan = 0; sh_bin = 0; sh_rank = 0; }
   for (int p = tid; p < P; p += UT) {
-    double Rc[9], H[36], b[6], LU[36], x6[6];
-    int piv[6];
-    mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
-    finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
-#pragma unroll
-    for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; }
-    const bool ok = lu6(LU, piv);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) x6[i] = b[i];
-    lu6_solve(LU, piv, x6);                                   // SVNICP.cpp:162
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { w.b[p * 6 + i] = b[i]; w.N[p * 6 + i] = ok ? x6[i] : __builtin_nan(""); }
     double lg[3];
     so3_log(a.R + 9 * p, lg);                                 // SVNICP.cpp:74-77
 #pragma unroll
@@ -782,7 +791,7 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
       w.x[p * 6 + i] = a.t[3 * p + i]; w.x[p * 6 + 3 + i] = lg[i];
     }
   }
-  __syncthreads();  // also makes this workgroup's global writes of H visible to its own reads below
+  __syncthreads();
 
   // pass 1 over the pairs: log-binned histogram
   const int n = P * P;
@@ -1357,7 +1366,7 @@ hipError_t launch_update_front(const UpdateArgs& a, hipStream_t st) {
   if (smem < (size_t)P * 36 * sizeof(double)) smem = (size_t)P * 36 * sizeof(double);  // second workgroup: H of every particle
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_front), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_upd_front, dim3(2), dim3(UT), smem, st, a);
+  hipLaunchKernelGGL(k_upd_front, dim3(2 + (P + 63) / 64), dim3(UT), smem, st, a);
   hipLaunchKernelGGL(k_upd_direction, dim3((P + 3) / 4), dim3(256), 0, st, a);
   if (a.check_early_stop || a.trH) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();

@@ -264,6 +264,7 @@ __device__ __forceinline__ float pack_slot3(float v, unsigned int bits) {  // (v
 __device__ __forceinline__ float fmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fmed3_raw(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float fmin3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 constexpr int kQueueCap = 1024;  // undecided pairs a workgroup can defer to its exact pass (4 KB of LDS)
 
 // exact float64 nearest-of-K of one (source point, particle) pair, candidate-parallel over G lanes (lane id `sub` in
@@ -434,7 +435,14 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
         }
         const bf8 bfr = split_b3(braw[cb]);
         const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
-        float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
+        // smallest and second smallest of the lane's 4*NRB packed scores.  Three scores give a (smallest, second) pair in
+        // two instructions (v_min3, v_med3); two such pairs are folded into the running pair in four (the second smallest
+        // of three pairs is min(med3 of the three smallest, the three seconds)): 8 instructions per 6 scores, where the
+        // one-at-a-time update (v_med3 + v_min per score) took 12 — these are the slow-issue instruction class.
+        float m1 = 0.0f, m2 = 0.0f, wp = 0.0f, rp = 0.0f, pend0 = 0.0f, pend1 = 0.0f;
+        int np = 0;            // scores waiting for a triple            (all three: compile-time after unrolling)
+        bool have_m = false;   // (m1, m2) hold a pair
+        bool have_p = false;   // (wp, rp) hold a pair waiting for its partner
         v4f dcur = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0], bfr, zero, 0, 0, 0);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {  // tile rb+1 goes to the matrix pipe before the VALU consumes tile rb
@@ -443,11 +451,33 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const float pk = pack_slot3(dcur[v], (unsigned int)(rb * 4 + v));
-            m2 = fmed3_raw(m1, m2, pk);
-            m1 = fmin_raw(m1, pk);
+            if (np == 0) { pend0 = pk; np = 1; }
+            else if (np == 1) { pend1 = pk; np = 2; }
+            else {
+              np = 0;
+              const float w = fmin3_raw(pend0, pend1, pk), r = fmed3_raw(pend0, pend1, pk);
+              if (!have_p) { wp = w; rp = r; have_p = true; }
+              else {
+                have_p = false;
+                if (!have_m) {      // first two triples: a plain merge of two pairs
+                  m1 = fmin_raw(wp, w);
+                  m2 = fmin3_raw(fmax_raw(wp, w), rp, r);
+                  have_m = true;
+                } else {
+                  const float md = fmed3_raw(m1, wp, w);
+                  m2 = fmin_raw(fmin3_raw(m2, rp, r), md);
+                  m1 = fmin3_raw(m1, wp, w);
+                }
+              }
+            }
           }
           dcur = dnext;
         }
+        // what is left over when 4*NRB is not a multiple of six
+        if (!have_m) { m1 = __builtin_huge_valf(); m2 = __builtin_huge_valf(); }
+        if (have_p) { const float t = fmax_raw(m1, wp); m1 = fmin_raw(m1, wp); m2 = fmin3_raw(t, m2, rp); }
+        if (np >= 1) { m2 = fmed3_raw(m1, m2, pend0); m1 = fmin_raw(m1, pend0); }
+        if (np >= 2) { m2 = fmed3_raw(m1, m2, pend1); m1 = fmin_raw(m1, pend1); }
         b1[cb] = m1; b2[cb] = m2;
       }
       // the four lanes that share a particle (lane groups mk = 0..3): a 4 x 4 transpose-reduce over the lane groups — after

@@ -365,6 +365,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "tp") ok = num(0, 1 << 16, &t.tp);
   else if (k == "debug") ok = num(0, 1, &t.debug);
   else if (k == "scan_split") ok = num(0, 16, &t.scan_split);
+  else if (k == "group_stride") ok = num(0, 1 << 30, &t.group_stride);
   else if (k == "correspondence") { if (v == "fast") t.full_corr = 0; else if (v == "full") t.full_corr = 1; else ok = false; }
   else return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: unknown option '" + k + "'");
   if (!ok) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: bad value '" + v + "' for option '" + k + "'");
@@ -550,6 +551,14 @@ static int stage_a(svnicp_ctx* c, const double* qsrc, const Pose0& pose, int K, 
       k.pool = c->pool2.p; k.out_idx = out_idx; k.out_d2 = out_d2;
       k.arena = c->arena.p; k.chunk_tab = c->chunk_tab.p; k.arena_cap = c->arena_cap; k.tab_rows = c->B;
       k.scan_split = c->tune.scan_split == 4 ? 4 : 8;
+      {  // a small stride coprime to n_groups: 17 sweeps over the curve (C3 1.04 -> 0.98 ms, C5 1.83 -> 1.65 ms against natural order)
+        const unsigned int ng = (unsigned int)((n + 63) / 64);
+        unsigned int st = c->tune.group_stride > 0 ? (unsigned int)c->tune.group_stride : 17u;
+        auto gcd = [](unsigned int x, unsigned int y) { while (y) { const unsigned int t = x % y; x = y; y = t; } return x; };
+        while (st > 1 && gcd(st, ng) != 1) st += 2;
+        if (ng <= 2 || st >= ng) st = 1;
+        k.group_stride = st;
+      }
       HIPCHK(c, hipMemsetAsync(c->chunk_tab.p, 0xff, ((size_t)c->B * kTilesChunks + 16 + (size_t)(c->B + 63) / 64 + 1) * sizeof(int32_t), c->stream));
       k.fail_list = c->fail_list.p; k.fail_count = c->fail_count.p; k.fail_tau = c->fail_tau.p; k.qrec = c->qrec.p;
       a.qthr = c->fail_tau.p;

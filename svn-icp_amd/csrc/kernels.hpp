@@ -80,6 +80,7 @@ struct KnnTilesArgs {
   int arena_cap;
   int64_t tab_rows;               // B of the allocation (rows of chunk_tab); after the table: the chunk allocation counter
   int scan_split;                 // waves per 64-query workgroup of the scan kernel: 4 or 8
+  unsigned int group_stride;      // scan kernel: workgroup i serves group (i * group_stride) mod n_groups (coprime to n_groups)
   int32_t* out_idx;
   double* out_d2;
   int32_t* fail_list;
@@ -147,6 +148,7 @@ struct Tuning {
   int fused_update_max_p = 128;  // above this the Stein step runs as workgroup-parallel kernels
   int wgpcu_search = 0, wgpcu_accum = 0;   // workgroups per CU the stage-B grids are sized for (0 = automatic)
   int tp = 0;                    // fused stage-B variants: source points per LDS tile (0 = automatic)
+  int group_stride = 0;          // stage A scan: group order stride (0 = default, 1 = natural order)
   int scan_split = 0;            // stage A scan: waves per 64-query workgroup, 4 or 8 (0 = default)
   int debug = 0;                 // print plans and per-phase cycle counters to stderr
   int full_corr = 0;             // 1: correspondence = full — per-particle exact NN over the whole target (SVGDICP.cpp:274-298)

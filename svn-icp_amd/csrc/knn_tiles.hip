@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnTilesArgs a) {
   unsigned char* scratch = smem + kShared + kScratch * wave;
   float2* lm = reinterpret_cast<float2*>(scratch);                 // seed: [QB][64] two minima
 
-  const int64_t q0 = a.b_lo + (int64_t)blockIdx.x * QW;  // first query position of the workgroup
+  const unsigned int grp = blockIdx.x;   // natural order: neighbouring groups share tiles in L2 (a strided order, as in the scan kernel, cost 5 % at C5)
+  const int64_t q0 = a.b_lo + (int64_t)grp * QW;  // first query position of the workgroup
   const int nq = (a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW;
   const double Et = __longlong_as_double((long long)*a.emax_bits);
 
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnTilesArgs a) {
   if (a.phase_cycles && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) atomicAdd(&a.phase_cycles[i], pacc[i]);
-    unsigned long long* pw = a.phase_cycles + 8 + 8 * ((size_t)blockIdx.x * WAVES + wave);  // per-wave record
+    unsigned long long* pw = a.phase_cycles + 8 + 8 * ((size_t)grp * WAVES + wave);  // per-wave record
 #pragma unroll
     for (int i = 0; i < 5; ++i) pw[i] = pacc[i];
   }
@@ -536,7 +537,11 @@ __global__ __launch_bounds__(64 * SW) void k_knn_scan_tiles(KnnTilesArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int S2 = a.S2, n_tiles = a.n_tiles;
   int2* queue = s_queue[wave];
-  const int64_t q0 = a.b_lo + (int64_t)blockIdx.x * QW;
+  // groups in a strided order: neighbours on the curve have similar work, and a run of heavy groups dispatched together
+  // at the end of the launch is what the kernel time would wait for
+  const unsigned int ngrp = gridDim.x;
+  const unsigned int grp = (unsigned int)(((unsigned long long)blockIdx.x * a.group_stride) % ngrp);
+  const int64_t q0 = a.b_lo + (int64_t)grp * QW;
   const int nq = (a.b_hi - q0) < QW ? (int)(a.b_hi - q0) : QW;
   QRec* recs = reinterpret_cast<QRec*>(a.qrec);
   unsigned long long tphase = a.phase_cycles ? __builtin_readcyclecounter() : 0ull;

@@ -60,7 +60,12 @@ typedef struct svnicp_params {
   int32_t struct_size;           /* = sizeof(svnicp_params)                                   */
   int32_t mode;                  /* SVNICP_MODE_*                                              */
   int32_t iterations;            /* SteinICPParam::iterations                                  */
-  int32_t knn_count;             /* SteinICPParam::KNN_count  (K_source_)                      */
+  int32_t knn_count;             /* SteinICPParam::KNN_count  (K_source_).  K <= 128: matrix-pipe
+                                  * search and Morton-tile stage A (the tuned path); larger K runs
+                                  * the LDS-tile kernels and is refused with SVNICP_ERR_INVALID in
+                                  * svnicp_align / svnicp_align_begin once the smallest tile no longer
+                                  * fits one CU's 160 KB of LDS (about K >= 330 for shards of <= 8
+                                  * particles, K >= 620 otherwise) */
   double lr;                     /* SteinICPParam::lr                                          */
   double max_dist;               /* SteinICPParam::max_dist                                    */
   double convergence_threshold;  /* SteinICPParam::convergence_threshold                       */

@@ -720,6 +720,7 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
     // one workgroup up to the same particle count as the SVN step; above it the workgroup-parallel chain (its median
     // select, one wavefront per particle for the Stein direction and the optimizer step)
     if (c->P > c->tune.fused_update_max_p) { u.svgd = 1; HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream)); }
+    else if (c->P >= 2 && !c->tune.update_fused) { u.svgd = 1; HIPCHK(c, launch_update_front(u, c->stream)); }   // median / gradients / directions on separate workgroups
     else HIPCHK(c, launch_update_svgd(u, c->stream));
   }
   else if (c->P > c->tune.fused_update_max_p) HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream));

@@ -727,7 +727,7 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
   if (blockIdx.x == 1) {
     // second workgroup: mean Hessian (SVNICP.cpp:85) and its inverse (linalg::inv, SVNICP.cpp:225), concurrently
     // with the median on the first one; the 6x6 LU is a long serial chain that nothing else should wait for
-    if (a.full_grad) return;
+    if (a.full_grad || a.svgd) return;
     double* lH = dyn;  // [P][36]
     for (int p = tid; p < P; p += UT) {
       double Rc[9], H[36], b[6];
@@ -764,6 +764,15 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
     // workgroups 2..: H, b and the Newton step of 64 particles each (SVNICP.cpp:146-162) — a 6x6 LU per thread, a long
     // serial chain that only k_upd_direction needs; it used to run ahead of the median on workgroup 0 (a third of its time)
     const int p = (blockIdx.x - 2) * 64 + tid;
+    if (a.svgd) {   // SVGD-ICP: the "Newton" slot carries the first-order gradient (SVGDICP.cpp:106-110), as in k_upd_prepare
+      if (tid < 64 && p < P) {
+        double g6[6];
+        svgd_gradient(a, p, g6);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) w.N[p * 6 + d] = g6[d];
+      }
+      return;
+    }
     if (tid < 64 && p < P) {
       double Rc[9], H[36], b[6], LU[36], x6[6];
       int piv[6];
@@ -783,6 +792,11 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
   for (int e = tid; e < HB_NB; e += UT) lh[e] = 0u;
   if (tid == 0) { sh_cnt = 0u; sh_nan = 0; sh_bin = 0; sh_rank = 0; }
   for (int p = tid; p < P; p += UT) {
+    if (a.svgd) {   // x is pose_particles_ as it stands (SVGDICP.cpp:106-110)
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { const double v = a.pose_out[d * P + p]; lx[p * 6 + d] = v; w.x[p * 6 + d] = v; }
+      continue;
+    }
     double lg[3];
     so3_log(a.R + 9 * p, lg);                                 // SVNICP.cpp:74-77
 #pragma unroll

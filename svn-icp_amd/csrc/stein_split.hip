@@ -570,8 +570,9 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
 // ---------------------------------------------------------------------------------------------
 // accumulation from the winner bytes
 // ---------------------------------------------------------------------------------------------
-// PLAIN: SVN mode without the correspondence trace (the timed configuration): no per-pair branches at all
-template <int PW, int WP, bool PLAIN>
+// PLAIN: no correspondence trace and no full-correspondence indices (the timed configurations): no per-pair branches at
+// all; SVGD: the first-order mode's count in place of one sum (compile-time with PLAIN, run-time flag otherwise)
+template <int PW, int WP, bool PLAIN, bool SVGD = false>
 __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
   if (a.ctl[0]) return;
   constexpr int BW = kWave / PW;
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
     acc[0] += w;
     acc[1] += w0; acc[2] += w1; acc[3] += w2;
     // SVGD mode needs count_nonzero(mask·Ts summed over xyz) (SVGDICP.cpp:404) instead of Σw·s_x²
-    if (!PLAIN && a.svgd) acc[4] += (((T0 + T1) + T2) != 0.0) ? mf : 0.0;
+    if (PLAIN ? SVGD : (a.svgd != 0)) acc[4] += (((T0 + T1) + T2) != 0.0) ? mf : 0.0;
     else acc[4] = fma(w0, n0, acc[4]);
     acc[5] = fma(w0, n1, acc[5]); acc[6] = fma(w0, n2, acc[6]);
     acc[7] = fma(w1, n1, acc[7]); acc[8] = fma(w1, n2, acc[8]); acc[9] = fma(w2, n2, acc[9]);
@@ -735,6 +736,7 @@ hipError_t launch_srb(const AccumPlan& plan, const AccumArgs& a, hipStream_t st)
 template <int PW, int WP>
 hipError_t launch_w(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
   if (!a.svgd && !a.corr && !a.full_idx) hipLaunchKernelGGL((k_stein_accumulate_w<PW, WP, true>), dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
+  else if (a.svgd && !a.corr && !a.full_idx) hipLaunchKernelGGL((k_stein_accumulate_w<PW, WP, true, true>), dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
   else hipLaunchKernelGGL((k_stein_accumulate_w<PW, WP, false>), dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
   return hipGetLastError();
 }

@@ -299,6 +299,27 @@ def test_stage_b_f32_search_is_bit_identical_to_f64_kernel(hip, P, full, K):
     np.testing.assert_allclose(out["split"][0], out["f64"][0], rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("P,B,M,K", [(8, 700, 20000, 16), (40, 2048, 16384, 100)])
+def test_map_frame_coordinates_far_from_the_origin(hip, orc, P, B, M, K):
+    """The local map lives in the map frame: kilometres from the origin after a long drive.  The float32 pre-filters of
+    both stages work on differences (stage A) and in the local frame of a point's first candidate (stage B), so their
+    error bounds grow with u*|coordinate|, not with its square; indices stay bit-exact, poses to 1e-9."""
+    src, tgt = hip.scans.random_clouds(B, M, seed=B + K)
+    off = np.array([4321.0, -8765.5, 120.25])
+    tgt = tgt + off
+    init = hip.scans.make_particles(P, seed=P) * 0.3
+    R0, t0 = hip.scans.rot_zyx(0.001, 0.002, -0.001), np.array([0.01, -0.02, 0.005]) + off   # initial guess carries the offset
+    cfg = dict(iterations=5, lr=1.0, max_dist=1.0, check_early_stop=False, convergence_threshold=1e-5, knn_count=K,
+               svn_full_grad=False)
+    o = orc.Solver(init, **cfg)
+    o.add_cloud(src, tgt, init); o.set_initial_mean(R0, t0)
+    tro = o.enable_trace(); o.stein_align()
+    s = _hip_solver(hip, init, **cfg)
+    s.add_cloud(src, tgt, init); s.set_initial_mean((R0, t0))
+    assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+    _compare(s, o, tro, P)
+
+
 def test_exact_ties_lowest_index_wins(hip, orc):
     """Integer-grid clouds: distances are exact and massively tied in stage A and stage B; the HIP
     path must break every tie like the reference CPU KNN (lowest index / first position)."""

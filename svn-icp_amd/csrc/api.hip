@@ -565,7 +565,7 @@ static int stage_a(svnicp_ctx* c, const double* qsrc, const Pose0& pose, int K, 
       if (c->prm.record_trace) { HIPCHK(c, c->stat_n.ensure((size_t)c->B)); k.stat_n = c->stat_n.p; }
       HIPCHK(c, hipMemsetAsync(c->fail_count.p, 0, sizeof(int), c->stream));
       unsigned long long*& dbg_phase = c->dbg_phase;
-      const size_t dbg_waves = (size_t)((n + 255) / 256) * 4;
+      const size_t dbg_waves = (size_t)((n + 63) / 64) * 4;   // seed kernel: four waves per 64-query group
       if (c->tune.debug && dbg_waves <= 65536) {   // larger launches are simply not instrumented
         if (!dbg_phase) HIPCHK(c, hipMalloc(&dbg_phase, (8 + 8 * 65536) * sizeof(unsigned long long)));
         HIPCHK(c, hipMemsetAsync(dbg_phase, 0, (8 + 8 * dbg_waves) * sizeof(unsigned long long), c->stream));
@@ -577,20 +577,16 @@ static int stage_a(svnicp_ctx* c, const double* qsrc, const Pose0& pose, int K, 
         HIPCHK(c, hipMemcpyAsync(h.data(), dbg_phase, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         fprintf(stderr, "[svnicp] k_knn_tiles wave cycles: rank %llu seed %llu scan %llu barrier waits + hand-over %llu | counts: seed tiles %llu scan tiles %llu scan (query, tile) pairs %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
-        std::vector<std::pair<unsigned long long, size_t>> tot;
-        for (size_t w = 0; w < dbg_waves; ++w) {
-          unsigned long long t = 0;
-          for (int i = 0; i < 4; ++i) t += h[8 + 8 * w + i];
-          tot.push_back({t, w});
-        }
-        std::sort(tot.begin(), tot.end());
-        auto show = [&](const char* tag, size_t k) {
-          const size_t w = tot[k].second;
-          const unsigned long long* r = &h[8 + 8 * w];
-          fprintf(stderr, "[svnicp]   %s wave %zu: total %llu = rank %llu seed %llu scan %llu wait %llu | seed tiles %llu scan tiles %llu (query, tile) pairs %llu survivors %llu\n", tag, w,
-                  tot[k].first, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        // per-wave records of k_knn_seed: [0] rank (wave 0 of a group only) [1] seed [3] barrier waits [5] tile loop [6] K-th bisection
+        auto column = [&](const char* tag, int col, unsigned long long floor_) {
+          std::vector<unsigned long long> v;
+          for (size_t w = 0; w < dbg_waves; ++w) { const unsigned long long x = h[8 + 8 * w + col]; if (x >= floor_) v.push_back(x); }
+          if (v.empty()) return;
+          std::sort(v.begin(), v.end());
+          fprintf(stderr, "[svnicp]   seed kernel %-12s n %6zu  p50 %8llu  p90 %8llu  p99 %8llu  max %8llu cycles\n", tag, v.size(), v[v.size() / 2],
+                  v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back());
         };
-        if (!tot.empty()) { show("median", tot.size() / 2); show("p90   ", tot.size() * 9 / 10); show("p99   ", tot.size() * 99 / 100); show("max   ", tot.size() - 1); }
+        column("rank", 0, 5000); column("seed", 1, 1); column("tile loop", 5, 1); column("bisection", 6, 1); column("waits", 3, 0);
       }
       HIPCHK(c, launch_fallback(c, a));
     }

@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnTilesArgs a) {
         }
       }
       wave_sync();
+      phase_mark(5);
       for (int q = 0; q < nb; ++q) {
         const float2 m = lm[q * kWave + lane];
         // K-th smallest of the 128 lane minima: bisection on the (non-negative) float bit patterns, 31 probes of
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnTilesArgs a) {
         }
         if (lane == 0) spare[qb0 + q] = (int)kth;  // K <= 128 witnesses with f32 distance <= this value
       }
+      phase_mark(6);
     }
     phase_mark(1);
     __syncthreads();
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnTilesArgs a) {
     for (int i = 0; i < 5; ++i) atomicAdd(&a.phase_cycles[i], pacc[i]);
     unsigned long long* pw = a.phase_cycles + 8 + 8 * ((size_t)grp * WAVES + wave);  // per-wave record
 #pragma unroll
-    for (int i = 0; i < 5; ++i) pw[i] = pacc[i];
+    for (int i = 0; i < 7; ++i) pw[i] = pacc[i];
   }
 }
 

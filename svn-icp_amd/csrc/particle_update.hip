@@ -1308,27 +1308,35 @@ __global__ void k_stats(StatsArgs a) {
   const int tid = threadIdx.x;
   const int P = a.P;
   __shared__ double mean[6];
+  // the sums below run over the particles in order, one thread per output: from LDS (a coalesced copy first) instead of
+  // 3 x P dependent global loads (48 -> 9 us at 128 particles); same order of additions, same bits
+  constexpr int kStage = 1024;
+  __shared__ double sp[6 * kStage];
+  const bool staged = P <= kStage;
+  if (staged) for (int e = tid; e < 6 * P; e += blockDim.x) sp[e] = a.pose[e];
+  __syncthreads();
+  const double* pose = staged ? sp : a.pose;
   // SVNICP.cpp:46: torch::ones({P,1}) / P is float32, promoted to f64 in the products
   const double wsvn = (double)(1.0f / (float)P);
   if (tid < 6) {
     double s = 0.0;
-    if (a.mode == 0) { for (int p = 0; p < P; ++p) s += a.pose[tid * P + p] * wsvn; }
-    else { for (int p = 0; p < P; ++p) s += a.pose[tid * P + p]; s /= P; }
+    if (a.mode == 0) { for (int p = 0; p < P; ++p) s += pose[tid * P + p] * wsvn; }
+    else { for (int p = 0; p < P; ++p) s += pose[tid * P + p]; s /= P; }
     mean[tid] = s;
     a.out[tid] = s;
   }
   __syncthreads();
   if (tid < 6) {
     double s = 0.0;
-    if (a.mode == 0) { for (int p = 0; p < P; ++p) { const double d = a.pose[tid * P + p] - mean[tid]; s += d * d * wsvn; } }
-    else { for (int p = 0; p < P; ++p) { const double d = a.pose[tid * P + p] - mean[tid]; s += d * d; } s /= (P - 1); }
+    if (a.mode == 0) { for (int p = 0; p < P; ++p) { const double d = pose[tid * P + p] - mean[tid]; s += d * d * wsvn; } }
+    else { for (int p = 0; p < P; ++p) { const double d = pose[tid * P + p] - mean[tid]; s += d * d; } s /= (P - 1); }
     a.out[6 + tid] = s;
   }
   if (tid < 36) {
     const int r = tid / 6, c = tid % 6;
     double s = 0.0;
     const double wgt = a.mode == 0 ? wsvn : 1.0;
-    for (int p = 0; p < P; ++p) s += wgt * ((a.pose[r * P + p] - mean[r]) * (a.pose[c * P + p] - mean[c]));
+    for (int p = 0; p < P; ++p) s += wgt * ((pose[r * P + p] - mean[r]) * (pose[c * P + p] - mean[c]));
     a.out[12 + tid] = a.mode == 0 ? s : s / P;
   }
   for (int p = tid; p < P; p += blockDim.x) a.out[48 + p] = a.mode == 0 ? wsvn : 1.0;
@@ -1415,7 +1423,7 @@ hipError_t launch_update_svgd(const UpdateArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_stats(const StatsArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_stats, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

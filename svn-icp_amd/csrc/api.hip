@@ -361,7 +361,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "search") { if (v == "bf16") t.search_f32 = 0; else if (v == "f32") t.search_f32 = 1; else ok = false; }
   else if (k == "update") { if (v == "auto") t.update_fused = 0; else if (v == "fused") t.update_fused = 1; else ok = false; }
   else if (k == "fused_update_max_p") ok = num(1, 700, &t.fused_update_max_p);   // P = 1 has no pair statistics; the fused kernel's LDS ends near P = 800
-  else if (k == "wgpcu") { int x = 0, y = 0; ok = sscanf(v.c_str(), "%d,%d", &x, &y) == 2 && x >= 0 && x <= 16 && y >= 0 && y <= 16; if (ok) { t.wgpcu_search = x; t.wgpcu_accum = y; } }
+  else if (k == "wgpcu") { int x = 0, y = 0; ok = sscanf(v.c_str(), "%d,%d", &x, &y) == 2 && x >= 0 && x <= 64 && y >= 0 && y <= 16; if (ok) { t.wgpcu_search = x; t.wgpcu_accum = y; } }
   else if (k == "tp") ok = num(0, 1 << 16, &t.tp);
   else if (k == "debug") ok = num(0, 1, &t.debug);
   else if (k == "scan_split") ok = num(0, 16, &t.scan_split);

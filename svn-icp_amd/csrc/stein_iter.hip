@@ -475,10 +475,11 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
     int occ_s = 4, occ_a = 3;
     pl.search_f32 = tune.search_f32 ? 1 : 0;
     split_occupancy_blocks(PW, WP, K, pl.smem, pl.search_f32 != 0, &occ_s, &occ_a);
-    if (tune.wgpcu_search >= 1 && tune.wgpcu_search <= 16 && tune.wgpcu_accum >= 1 && tune.wgpcu_accum <= 16) {
+    if (tune.wgpcu_search >= 1 && tune.wgpcu_search <= 64 && tune.wgpcu_accum >= 1 && tune.wgpcu_accum <= 16) {
       occ_s = tune.wgpcu_search; occ_a = tune.wgpcu_accum;   // profiling knob
-    } else {  // measured at C3: the barrier-free search kernel balances best with two rounds of smaller workgroups;
-      occ_s *= 2;                        // the accumulate kernel pays per workgroup in k_reduce_partials: 4 per CU
+    } else {  // measured at C3: the barrier-free search kernel balances best with about four rounds of smaller workgroups
+      occ_s *= 4;                        // (4.65 ms per registration at two rounds, 4.55 at four to twelve, 4.73 at sixteen);
+                                         // the accumulate kernel pays per workgroup in k_reduce_partials: 4 per CU
       if (occ_a > 4) occ_a = 4;
     }
     size_grid(occ_a, &pl.grid_x, &pl.pts_per_block);

@@ -1,12 +1,8 @@
-# stage-B profiling knobs on one workload: prints the plan and the per-class GPU times for each setting
+# stage-B profiling knobs on one workload: prints the per-class GPU times for each setting (search, accumulate workgroups per CU)
 cd $GRAFT_REPO_ROOT
 w=${1:-C3}
-run() { echo "== $*" >> gpurun_out/knobs.log; env SVNICP_OPTIONS="debug=1;$1" timeout -k 10 200 python tests/gpu_time_knn.py $w 2>&1 | grep -E "stage-B plan|stage_a" | tail -2 >> gpurun_out/knobs.log; }
+run() { echo "== $*" >> gpurun_out/knobs.log; env SVNICP_OPTIONS="$1" timeout -k 10 200 python tests/gpu_time_knn.py $w 2>&1 | grep -E "stage_a" | tail -1 | cut -c1-200 >> gpurun_out/knobs.log; }
 : > gpurun_out/knobs.log
-run X=0
-run wgpcu=10,4
-run wgpcu=10,2
-run wgpcu=10,6
-run wgpcu=8,3
-run wgpcu=12,3
-run wgpcu=15,3
+for s in 16 24 32 48 64; do run "wgpcu=$s,4"; done
+
+cat gpurun_out/knobs.log

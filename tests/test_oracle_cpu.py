@@ -134,6 +134,31 @@ def test_oracle_vs_torch_restatement_live(orc, pkg, P, full):
     assert np.allclose(o.get_cov_matrix(), s.get_cov_matrix().numpy(), atol=TIGHT)
 
 
+def test_oracle_full_correspondence_is_a_k1_search_over_the_whole_target(orc, pkg):
+    """orc_set_correspondence_full restates SVGDICP::get_correspondence (SVGDICP.cpp:274-298): with K = 1 the index the
+    reference's KNearestNeighborIdx returns is the argmin of the squared distances in target order (knn_cpu.cpp:35-67,
+    pinned above).  First iteration, numpy brute force on the same transformed points."""
+    src, tgt = pkg.scans.random_clouds(120, 400, seed=31)
+    P = 4
+    init = pkg.scans.make_particles(P, seed=31) * 0.3
+    o = orc.Solver(init, iterations=2, lr=1.0, max_dist=1.0, knn_count=6, svn_full_grad=False)
+    o.set_correspondence_full(True)
+    o.add_cloud(src, tgt, init)
+    tro = o.enable_trace(); o.stein_align()
+    for p in range(P):
+        R = so3_exp_np(init[3:, p])
+        T = (src[:, 0:1] * R[:, 0] + src[:, 1:2] * R[:, 1] + src[:, 2:3] * R[:, 2]) + init[:3, p]     # SVNICP.cpp:62-64, R0 = I, t0 = 0
+        d = T[:, None, :] - tgt[None, :, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        assert np.array_equal(tro["corr"][0, p], np.argmin(d2, axis=1))
+    # the fast routine restricts the same search to the K candidates of the initial pose: where it disagrees, its winner is farther
+    o2 = orc.Solver(init, iterations=2, lr=1.0, max_dist=1.0, knn_count=6, svn_full_grad=False)
+    o2.add_cloud(src, tgt, init)
+    tr2 = o2.enable_trace(); o2.stein_align()
+    fast_idx = np.take_along_axis(o2.candidates()[None, :, :].repeat(P, 0), tr2["corr"][0][..., None].astype(np.int64), axis=2)[..., 0]
+    assert (fast_idx == tro["corr"][0]).mean() > 0.5
+
+
 def test_oracle_recovers_planted_transform(orc, pkg):
     off = (0.05, -0.03, 0.02, 0.004, -0.003, 0.006)
     src, tgt = pkg.scans.random_clouds(2000, 6000, seed=4, offset=off)

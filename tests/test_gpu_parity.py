@@ -267,6 +267,26 @@ def test_stage_a_fallback_on_pool_overflow(hip, orc, sliced_max, K):
     assert np.array_equal(s.get_candidate_dist2(), od)
 
 
+def test_stage_a_survivor_arena_exhaustion_is_survivable(hip, orc):
+    """Every query sits next to 2000 duplicated targets: each needs three 512-slot chunks beyond its own pool row, 40 000
+    queries ask for 120 000 chunks and the arena holds 32 768.  Queries that get no chunk are marked failed (no hang, no
+    write outside the arena) and redone exactly by the fallback together with the rest (more than 512 exact ties each)."""
+    rng = np.random.default_rng(5)
+    centers = rng.normal(size=(6, 3)) * 5
+    tgt = np.repeat(centers, 2000, axis=0).astype(np.float32).astype(np.float64)
+    tgt = tgt[rng.permutation(tgt.shape[0])]
+    B = 40000
+    src = centers[rng.integers(0, 6, B)] + rng.normal(size=(B, 3)) * 0.1
+    init = np.zeros((6, 1))
+    s = _hip_solver(hip, init, trace=False, iterations=1, lr=1.0, max_dist=1.0, knn_count=8, svn_full_grad=False)
+    s.add_cloud(src, tgt, init)
+    s.stein_align()
+    assert s.get_knn_fallbacks() == B
+    oi, od = orc.knn_topk(src, tgt, 8)
+    assert np.array_equal(s.get_candidates().astype(np.int64), oi)
+    assert np.array_equal(s.get_candidate_dist2(), od)
+
+
 @pytest.mark.parametrize("P,full,K", [(70, False, 60), (20, True, 60), (128, False, 100), (9, False, 128), (40, False, 17),
                                       (33, False, 1), (65, False, 80), (17, False, 97), (30, False, 112)])
 def test_stage_b_f32_search_is_bit_identical_to_f64_kernel(hip, P, full, K):

@@ -573,7 +573,9 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
 // PLAIN: no correspondence trace and no full-correspondence indices (the timed configurations): no per-pair branches at
 // all; SVGD: the first-order mode's count in place of one sum (compile-time with PLAIN, run-time flag otherwise)
 template <int PW, int WP, bool PLAIN, bool SVGD = false>
-__global__ __launch_bounds__(NT, 3) void k_stein_accumulate_w(AccumArgs a) {
+// launch bounds: the plain SVN variant reaches 127 VGPRs (four waves per SIMD) on its own and schedules worse when forced
+// (80 -> 91 us); the plain SVGD variant needs the bound to come down from 135 (92 -> 82 us)
+__global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulate_w(AccumArgs a) {
   if (a.ctl[0]) return;
   constexpr int BW = kWave / PW;
   constexpr int WB = 4 / WP;

@@ -109,16 +109,24 @@ __global__ __launch_bounds__(256) void k_map_place(const unsigned int* __restric
 
 __global__ __launch_bounds__(256) void k_map_count(const unsigned int* __restrict__ sslot, int64_t n, int* __restrict__ counts,
                                                    int max_points, int* __restrict__ stats) {
+  __shared__ int s_new;
+  if (threadIdx.x == 0) s_new = 0;
+  __syncthreads();
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const unsigned int s = sslot[j];
-  if (s == 0xffffffffu || (j > 0 && sslot[j - 1] == s)) return;   // one thread per run
-  int64_t e = j + 1;
-  while (e < n && sslot[e] == s) ++e;   // runs are short (a voxel holds a few points of one scan)
-  const int before = counts[s];
-  const int64_t after = before + (e - j);
-  counts[s] = after > max_points ? max_points : (int)after;
-  if (before == 0) atomicAdd(&stats[0], 1);
+  if (j < n) {
+    const unsigned int s = sslot[j];
+    if (s != 0xffffffffu && (j == 0 || sslot[j - 1] != s)) {   // one thread per run
+      // a voxel next to the sensor takes thousands of points of one scan: the run's end by bisection, not by walking it
+      int64_t lo = j + 1, hi = n;
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sslot[mid] <= s) lo = mid + 1; else hi = mid; }
+      const int before = counts[s];
+      const int64_t after = before + (lo - j);
+      counts[s] = after > max_points ? max_points : (int)after;
+      if (before == 0) atomicAdd(&s_new, 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_new) atomicAdd(&stats[0], s_new);   // one global atomic per workgroup
 }
 
 // RemoveFarPointCloud (VoxelHashMap.cpp:89-97)
@@ -138,39 +146,57 @@ __global__ __launch_bounds__(256) void k_map_remove_far(unsigned long long* __re
 }
 
 // GetMap(pose, r) selection (VoxelHashMap.cpp:48-58); r2 < 0 selects every voxel (GetMap(), :44-46)
+constexpr int kSelChunk = 16;   // slots per thread of k_map_select
 __global__ __launch_bounds__(256) void k_map_select(const unsigned long long* __restrict__ keys, const int* __restrict__ counts,
                                                     const float* __restrict__ pts, int64_t cap, int max_points, double px, double py,
                                                     double pz, double r2, unsigned long long* __restrict__ sel_key,
-                                                    unsigned int* __restrict__ sel_slot, int* __restrict__ nsel) {
+                                                    unsigned int* __restrict__ sel_slot, int* __restrict__ nsel, int limit) {
+  // a workgroup owns kSelChunk * 256 consecutive slots: it counts its selected voxels, reserves their output range with ONE
+  // global atomic (4096 workgroups with one atomic each on the same address took 45 us) and writes them (any order: the
+  // keys are sorted afterwards)
   __shared__ int s_base, s_n;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool take = false;
-  unsigned long long k = 0;
-  if (s < cap) {
-    k = keys[s];
-    if (k != kEmpty && k != kTomb && counts[s] > 0) {
-      take = true;
+  const int64_t s0 = (int64_t)blockIdx.x * (kSelChunk * 256) + threadIdx.x;
+  unsigned int takes = 0;
+  unsigned long long k[kSelChunk];
+#pragma unroll
+  for (int i = 0; i < kSelChunk; ++i) {
+    const int64_t s = s0 + (int64_t)i * 256;
+    k[i] = s < cap ? keys[s] : kEmpty;
+  }
+#pragma unroll
+  for (int i = 0; i < kSelChunk; ++i) {
+    const int64_t s = s0 + (int64_t)i * 256;
+    if (k[i] != kEmpty && k[i] != kTomb && counts[s] > 0) {
+      bool take = true;
       if (r2 >= 0.0) {
         const float* f = pts + (size_t)s * max_points * 3;
         const double dx = (double)f[0] - px, dy = (double)f[1] - py, dz = (double)f[2] - pz;
         take = dx * dx + dy * dy + dz * dz < r2;
       }
+      if (take) takes |= 1u << i;
     }
   }
   int my = 0;
-  if (take) my = atomicAdd(&s_n, 1);
+  if (takes) my = atomicAdd(&s_n, __popc(takes));
   __syncthreads();
-  if (threadIdx.x == 0 && s_n > 0) s_base = atomicAdd(nsel, s_n);   // one global atomic per workgroup
+  if (threadIdx.x == 0 && s_n > 0) s_base = atomicAdd(nsel, s_n);
   __syncthreads();
-  if (take) { sel_key[s_base + my] = k; sel_slot[s_base + my] = (unsigned int)s; }
+  int pos = s_base + my;
+#pragma unroll
+  for (int i = 0; i < kSelChunk; ++i) {
+    if ((takes >> i) & 1u) {
+      if (pos < limit) { sel_key[pos] = k[i]; sel_slot[pos] = (unsigned int)(s0 + (int64_t)i * 256); }   // limit = live voxels known to the host: never exceeded
+      ++pos;
+    }
+  }
 }
 
-__global__ __launch_bounds__(256) void k_map_sel_counts(const unsigned int* __restrict__ sslot, int nsel, const int* __restrict__ counts,
-                                                        int* __restrict__ cnt_out) {
+__global__ __launch_bounds__(256) void k_map_sel_counts(const unsigned long long* __restrict__ skey, const unsigned int* __restrict__ sslot, int nsel,
+                                                        const int* __restrict__ counts, int* __restrict__ cnt_out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nsel) cnt_out[j] = counts[sslot[j]];
+  if (j < nsel) cnt_out[j] = skey[j] == kEmpty ? 0 : counts[sslot[j]];   // entries the selection did not fill sort to the end with key ~0
 }
 
 // voxel j of the sorted selection -> its points as float64 rows (ICPUtils.cpp:27-43 widening) at offs[j]
@@ -216,6 +242,9 @@ struct Buf {
   hipError_t ensure(size_t n) {
     if (n <= cap && p) return hipSuccess;
     if (p) (void)hipFree(p);
+    // grow by half beyond the request: the map gains voxels with every scan, and a hipFree + hipMalloc per call cost more
+    // than the kernels of a query
+    if (cap > 0) n += n / 2;
     p = nullptr; cap = 0;
     if (n == 0) n = 1;
     const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
@@ -402,40 +431,39 @@ int svnicp_map_query(svnicp_map* m, const double center[3], double max_range, in
   MCHK(m, hipSetDevice(m->device));
   const double r2 = (center && max_range >= 0.0) ? max_range * max_range : -1.0;
   const double c0 = center ? center[0] : 0.0, c1 = center ? center[1] : 0.0, c2 = center ? center[2] : 0.0;
-  int rc = read_stats(m);
-  if (rc) return rc;
+  // Everything is sized by the number of live voxels the host already knows (every call that changes the map ends by
+  // reading the statistics), so the whole query is queued without looking at intermediate counts and synchronises once:
+  // unselected entries keep the key ~0, sort to the end and count zero points.
   const size_t live = (size_t)(m->h_stats[0] > 0 ? m->h_stats[0] : 0);
   *count_out = 0; m->last_M = 0;
   if (live == 0) return SVNICP_OK;
   MCHK(m, m->sel_key.ensure(live)); MCHK(m, m->sel_key2.ensure(live)); MCHK(m, m->sel_slot.ensure(live)); MCHK(m, m->sel_slot2.ensure(live));
   MCHK(m, m->sel_cnt.ensure(live)); MCHK(m, m->sel_off.ensure(live));
-  MCHK(m, hipMemsetAsync(m->nsel.p, 0, sizeof(int), m->stream));
-  hipLaunchKernelGGL(k_map_select, dim3((unsigned)((m->cap + 255) / 256)), dim3(256), 0, m->stream, m->keys.p, m->counts.p, m->pts.p, m->cap,
-                     m->max_points, c0, c1, c2, r2, m->sel_key.p, m->sel_slot.p, m->nsel.p);
-  MCHK(m, hipGetLastError());
-  int nsel = 0;
-  MCHK(m, hipMemcpyAsync(&nsel, m->nsel.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-  MCHK(m, hipStreamSynchronize(m->stream));
-  if (nsel <= 0) return SVNICP_OK;
+  MCHK(m, m->out.ensure(live * (size_t)m->max_points * 3));
   size_t b1 = 0, b2 = 0;
-  MCHK(m, rocprim::radix_sort_pairs(nullptr, b1, m->sel_key.p, m->sel_key2.p, m->sel_slot.p, m->sel_slot2.p, (size_t)nsel, 0, 63, m->stream));
-  MCHK(m, rocprim::exclusive_scan(nullptr, b2, m->sel_cnt.p, m->sel_off.p, 0, (size_t)nsel, rocprim::plus<int>(), m->stream));
+  MCHK(m, rocprim::radix_sort_pairs(nullptr, b1, m->sel_key.p, m->sel_key2.p, m->sel_slot.p, m->sel_slot2.p, live, 0, 64, m->stream));
+  MCHK(m, rocprim::exclusive_scan(nullptr, b2, m->sel_cnt.p, m->sel_off.p, 0, live, rocprim::plus<int>(), m->stream));
   MCHK(m, m->tmp.ensure(b1 > b2 ? b1 : b2));
-  MCHK(m, rocprim::radix_sort_pairs(m->tmp.p, b1, m->sel_key.p, m->sel_key2.p, m->sel_slot.p, m->sel_slot2.p, (size_t)nsel, 0, 63, m->stream));
-  hipLaunchKernelGGL(k_map_sel_counts, dim3((unsigned)((nsel + 255) / 256)), dim3(256), 0, m->stream, m->sel_slot2.p, nsel, m->counts.p, m->sel_cnt.p);
+  MCHK(m, hipMemsetAsync(m->nsel.p, 0, sizeof(int), m->stream));
+  MCHK(m, hipMemsetAsync(m->sel_key.p, 0xff, live * sizeof(unsigned long long), m->stream));
+  MCHK(m, hipMemsetAsync(m->sel_slot.p, 0, live * sizeof(unsigned int), m->stream));
+  hipLaunchKernelGGL(k_map_select, dim3((unsigned)((m->cap + kSelChunk * 256 - 1) / (kSelChunk * 256))), dim3(256), 0, m->stream, m->keys.p, m->counts.p, m->pts.p, m->cap,
+                     m->max_points, c0, c1, c2, r2, m->sel_key.p, m->sel_slot.p, m->nsel.p, (int)live);
   MCHK(m, hipGetLastError());
-  MCHK(m, rocprim::exclusive_scan(m->tmp.p, b2, m->sel_cnt.p, m->sel_off.p, 0, (size_t)nsel, rocprim::plus<int>(), m->stream));
-  int last[2] = {0, 0};
-  MCHK(m, hipMemcpyAsync(&last[0], m->sel_off.p + (nsel - 1), sizeof(int), hipMemcpyDeviceToHost, m->stream));
-  MCHK(m, hipMemcpyAsync(&last[1], m->sel_cnt.p + (nsel - 1), sizeof(int), hipMemcpyDeviceToHost, m->stream));
-  MCHK(m, hipStreamSynchronize(m->stream));
-  const int64_t M = (int64_t)last[0] + last[1];
-  MCHK(m, m->out.ensure((size_t)M * 3));
-  const int64_t work = (int64_t)nsel * m->max_points;
-  hipLaunchKernelGGL(k_map_gather, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, m->stream, m->sel_slot2.p, m->sel_off.p, m->sel_cnt.p, nsel,
+  MCHK(m, rocprim::radix_sort_pairs(m->tmp.p, b1, m->sel_key.p, m->sel_key2.p, m->sel_slot.p, m->sel_slot2.p, live, 0, 64, m->stream));
+  const int nl = (int)live;
+  hipLaunchKernelGGL(k_map_sel_counts, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, m->stream, m->sel_key2.p, m->sel_slot2.p, nl, m->counts.p, m->sel_cnt.p);
+  MCHK(m, hipGetLastError());
+  MCHK(m, rocprim::exclusive_scan(m->tmp.p, b2, m->sel_cnt.p, m->sel_off.p, 0, live, rocprim::plus<int>(), m->stream));
+  const int64_t work = (int64_t)live * m->max_points;
+  hipLaunchKernelGGL(k_map_gather, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, m->stream, m->sel_slot2.p, m->sel_off.p, m->sel_cnt.p, nl,
                      m->max_points, m->pts.p, m->out.p, (float*)nullptr);
   MCHK(m, hipGetLastError());
+  int last[2] = {0, 0};
+  MCHK(m, hipMemcpyAsync(&last[0], m->sel_off.p + (live - 1), sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  MCHK(m, hipMemcpyAsync(&last[1], m->sel_cnt.p + (live - 1), sizeof(int), hipMemcpyDeviceToHost, m->stream));
   MCHK(m, hipStreamSynchronize(m->stream));   // the rows are complete when the call returns (another stream may read them)
+  const int64_t M = (int64_t)last[0] + last[1];
   m->last_M = M;
   *count_out = M;
   return SVNICP_OK;

@@ -1,0 +1,27 @@
+"""bring-up timing helper (not a pytest file): scan-to-map loop (svn-icp_amd/pipeline.py, device map) on synthetic scans.
+Prints wall time per scan split into pre-processing + map query + cloud hand-over / registration + map insertion."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+pkg = g.load_package()
+from svnicp_amd.pipeline import RegistrationPipeline, PipelineConfig
+sc = pkg.scans
+scene = sc.make_scene(sc.SEED)
+n_pts = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+gpu_map = (sys.argv[3] if len(sys.argv) > 3 else "1") == "1"
+cfg = PipelineConfig(particle_count=P, gpu_map=gpu_map)
+pipe = RegistrationPipeline(cfg)
+pre, ali, tot = [], [], []
+for i in range(12):
+    t = np.array([0.3 * i, 0.0, 0.0])
+    pts = sc.lidar_scan(scene, np.eye(3), t, n_pts, stream=300 + i)
+    t0 = time.perf_counter()
+    r = pipe.process_scan(pts, 0.1 * i)
+    t1 = time.perf_counter()
+    pre.append(r.preprocessing_s); ali.append(r.align_s); tot.append(t1 - t0)
+    if i == 11:
+        print("last pose x %.3f (truth %.3f)" % (r.pose[0, 3], 0.3 * i))
+print("scan of %d points, %d particles, gpu_map=%s: per scan median total %.2f ms = pre-processing+query+hand-over %.2f + align+insert %.2f; H2D %.1f MB in all" % (
+    n_pts, P, gpu_map, 1e3 * np.median(tot[3:]), 1e3 * np.median(pre[3:]), 1e3 * np.median(ali[3:]), pipe.bytes_h2d / 1e6))

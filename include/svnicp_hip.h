@@ -210,6 +210,26 @@ int svnicp_get_ambiguous_steps(svnicp_ctx *ctx, int *out);
 int svnicp_set_profile(svnicp_ctx *ctx, int on);
 int svnicp_get_kernel_ms(svnicp_ctx *ctx, double *ms6, int32_t *launches6);
 
+/* ---- per-scan pre-processing on the device ------------------------------------------------
+ * What OdometryPipeline::ICP_processing does to a scan before the solver sees it (src/core/OdometryPipeline.cpp):
+ * crop_pointcloud (:692-704), pcl::UniformSampling at 0.5 * voxel_size for the local map (:559, :684-690) and at
+ * 1.5 * voxel_size of that cloud for the solver (:560).  The raw float32 scan is uploaded once; the three clouds stay in
+ * device memory for svnicp_map_add_cloud(..., SVNICP_MEM_DEVICE) and svnicp_set_source(..., SVNICP_MEM_DEVICE).
+ * Leaves are emitted in ascending linear index, the point closest to a leaf centre survives, first in input order on
+ * ties (svn-icp_amd/host/registration_pipeline.hpp: downsample_uniform).  scan_max_range: in/out, the largest SQUARED
+ * norm seen so far (:699, kept as the reference keeps it).  The counts are valid until the next svnicp_prep_scan. */
+typedef struct svnicp_prep svnicp_prep;
+int svnicp_prep_create(int device, svnicp_prep **out);
+void svnicp_prep_destroy(svnicp_prep *prep);
+const char *svnicp_prep_last_error(const svnicp_prep *prep);
+int svnicp_prep_scan(svnicp_prep *prep, const float *xyz, int64_t n, int mem_kind, double min_range, double max_range,
+                     double voxel_size, double *scan_max_range, int64_t *n_cropped, int64_t *n_map, int64_t *n_source);
+const float *svnicp_prep_cropped_devptr(svnicp_prep *prep);    /* float32 [n_cropped][3] */
+const float *svnicp_prep_map_cloud_devptr(svnicp_prep *prep);  /* float32 [n_map][3]     */
+const double *svnicp_prep_source_devptr(svnicp_prep *prep);    /* float64 [n_source][3]  */
+int svnicp_prep_download(svnicp_prep *prep, int which /* 0 cropped, 1 map cloud, 2 source */, float *out_xyz,
+                         int64_t cap_points, int64_t *n_out);   /* test tap */
+
 #ifdef __cplusplus
 }
 #endif

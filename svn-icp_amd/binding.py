@@ -83,6 +83,17 @@ def load_library():
     L.svnicp_map_points_devptr.argtypes = [vp]
     L.svnicp_map_points_devptr.restype = vp
     L.svnicp_map_download.argtypes = [vp, dp, C.c_int64, C.POINTER(C.c_int64)]
+    L.svnicp_prep_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.svnicp_prep_destroy.argtypes = [vp]
+    L.svnicp_prep_destroy.restype = None
+    L.svnicp_prep_last_error.argtypes = [vp]
+    L.svnicp_prep_last_error.restype = C.c_char_p
+    L.svnicp_prep_scan.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, dp, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    for name in ("svnicp_prep_cropped_devptr", "svnicp_prep_map_cloud_devptr", "svnicp_prep_source_devptr"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = vp
+    L.svnicp_prep_download.argtypes = [vp, C.c_int, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.svnicp_set_initial_mean.argtypes = [vp, dp, dp]
     L.svnicp_set_k.argtypes = [vp, C.c_int]
     L.svnicp_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]

@@ -95,7 +95,7 @@ def crop_pointcloud(points: np.ndarray, min_range: float, max_range: float, scan
     Also returns the updated ``scan_max_range_`` — which the reference sets to the largest SQUARED norm seen
     (:699) and later uses as a length (:578); mirrored as is."""
     p = np.asarray(points, float)[:, :3]
-    n2 = np.einsum("ij,ij->i", p, p)
+    n2 = (p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) + p[:, 2] * p[:, 2]     # the order of the C++ and device versions
     keep = (n2 < max_range * max_range) & (n2 > min_range * min_range)
     if n2.size:
         scan_max_range = max(scan_max_range, float(n2.max()))
@@ -116,7 +116,8 @@ def downsample_uniform(points: np.ndarray, radius: float) -> np.ndarray:
     ijk = np.floor(p * inv).astype(np.int64) - mn
     leaf = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
     centre = (ijk + mn + 0.5) * radius
-    d2 = np.einsum("ij,ij->i", p - centre, p - centre)
+    e = p - centre
+    d2 = (e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]) + e[:, 2] * e[:, 2]
     order = np.lexsort((np.arange(p.shape[0]), d2, leaf))   # by leaf, then distance to the centre, then input order
     first = np.ones(order.size, bool)
     first[1:] = leaf[order][1:] != leaf[order][:-1]
@@ -188,6 +189,16 @@ class DeviceVoxelHashMap:
                                                t.ctypes.data_as(dp)), "svnicp_map_add_cloud")
         self.bytes_uploaded += pts.nbytes
 
+    def add_pointcloud_device(self, devptr: int, n: int, pose: np.ndarray):
+        """add_pointcloud for float32 rows that already live in HBM (DevicePreprocessor)."""
+        C = self._C
+        T = np.asarray(pose, float)
+        R = np.ascontiguousarray(T[:3, :3]).reshape(9)
+        t = np.ascontiguousarray(T[:3, 3])
+        dp = C.POINTER(C.c_double)
+        self._chk(self._L.svnicp_map_add_cloud(self._h, C.c_void_p(int(devptr)), int(n), 1, R.ctypes.data_as(dp), t.ctypes.data_as(dp)),
+                  "svnicp_map_add_cloud")
+
     def get_map(self, pose=None, max_range: float | None = None):
         """-> (device pointer of float64 [M][3], M)"""
         C = self._C
@@ -209,6 +220,71 @@ class DeviceVoxelHashMap:
         if out.size:
             self._chk(self._L.svnicp_map_download(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), out.shape[0], C.byref(n)),
                       "svnicp_map_download")
+        return out
+
+
+class DevicePreprocessor:
+    """crop_pointcloud + the two uniform samplings of a scan on the device (svnicp_prep_* of the C ABI, csrc/scan_prep.hip):
+    the raw float32 scan is uploaded once, the cropped cloud, the map cloud (float32) and the source cloud (float64 rows)
+    stay in HBM.  Same points in the same order as crop_pointcloud / downsample_uniform above."""
+
+    def __init__(self, device: int = 0):
+        import ctypes as C
+        from . import binding
+        self._C = C
+        self._L = binding.load_library()
+        self._h = C.c_void_p()
+        rc = self._L.svnicp_prep_create(int(device), C.byref(self._h))
+        if rc:
+            raise binding.SvnIcpError(f"svnicp_prep_create failed ({rc}): {self._L.svnicp_prep_last_error(None).decode()}")
+        self.n_cropped = self.n_map = self.n_source = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.svnicp_prep_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scan(self, points: np.ndarray, min_range: float, max_range: float, voxel_size: float, scan_max_range: float) -> float:
+        """-> updated scan_max_range; counts in n_cropped / n_map / n_source, clouds behind the *_ptr properties."""
+        from . import binding
+        C = self._C
+        pts = np.ascontiguousarray(np.asarray(points, np.float32)[:, :3])
+        smr = C.c_double(float(scan_max_range))
+        nc, nm, ns = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        rc = self._L.svnicp_prep_scan(self._h, pts.ctypes.data_as(C.c_void_p), pts.shape[0], 0, float(min_range), float(max_range),
+                                      float(voxel_size), C.byref(smr), C.byref(nc), C.byref(nm), C.byref(ns))
+        if rc:
+            raise binding.SvnIcpError(f"svnicp_prep_scan failed ({rc}): {self._L.svnicp_prep_last_error(self._h).decode()}")
+        self.n_cropped, self.n_map, self.n_source = int(nc.value), int(nm.value), int(ns.value)
+        self.bytes_uploaded = pts.nbytes
+        return float(smr.value)
+
+    @property
+    def cropped_ptr(self) -> int:
+        return int(self._L.svnicp_prep_cropped_devptr(self._h) or 0)
+
+    @property
+    def map_cloud_ptr(self) -> int:
+        return int(self._L.svnicp_prep_map_cloud_devptr(self._h) or 0)
+
+    @property
+    def source_ptr(self) -> int:
+        return int(self._L.svnicp_prep_source_devptr(self._h) or 0)
+
+    def download(self, which: int) -> np.ndarray:
+        """0 cropped, 1 map cloud, 2 source — float32 rows (test tap)."""
+        C = self._C
+        n = C.c_int64(0)
+        self._L.svnicp_prep_download(self._h, int(which), None, 0, C.byref(n))
+        out = np.zeros((int(n.value), 3), np.float32)
+        if out.size:
+            self._L.svnicp_prep_download(self._h, int(which), out.ctypes.data_as(C.c_void_p), out.shape[0], C.byref(n))
         return out
 
 
@@ -300,6 +376,7 @@ class PipelineConfig:
     map_range: float = 100.0
     particle_count: int = 128
     gpu_map: bool = False          # keep the local map in HBM (DeviceVoxelHashMap): the target never crosses PCIe
+    gpu_prep: bool = False         # with gpu_map: crop and both uniform samplings on the device (DevicePreprocessor): the raw scan is uploaded, no host pass over the points
     solver: SteinICPParam = field(default_factory=lambda: SteinICPParam(iterations=20, lr=1.0, max_dist=1.0, KNN_count=100))
     seed: int = 0
 
@@ -334,6 +411,7 @@ class RegistrationPipeline:
         self.scan_max_range = 0.0
         self._rng = np.random.default_rng(self.cfg.seed)
         self._solver: SVNICP | None = None
+        self._prep: DevicePreprocessor | None = None
 
     def _particles(self) -> np.ndarray:
         return initialize_particles(self.cfg.particle_count, PRIOR_UB, PRIOR_LB, self._rng)   # set_initPose, :661-667
@@ -341,13 +419,23 @@ class RegistrationPipeline:
     def process_scan(self, points: np.ndarray, stamp: float) -> ScanResult:
         c = self.cfg
         t0 = time.perf_counter()
-        cropped, self.scan_max_range = crop_pointcloud(points, c.min_range, c.max_range, self.scan_max_range)   # :556
-        to_map = downsample_uniform(cropped, 0.5 * c.voxel_size)                                                # :559
-        source = downsample_uniform(to_map, 1.5 * c.voxel_size)                                                 # :560
+        dev = c.gpu_map and c.gpu_prep
+        if dev:
+            if self._prep is None:
+                self._prep = DevicePreprocessor(self.device)
+            self.scan_max_range = self._prep.scan(points, c.min_range, c.max_range, c.voxel_size, self.scan_max_range)  # :556-560
+            self.bytes_h2d += self._prep.bytes_uploaded
+        else:
+            cropped, self.scan_max_range = crop_pointcloud(points, c.min_range, c.max_range, self.scan_max_range)   # :556
+            to_map = downsample_uniform(cropped, 0.5 * c.voxel_size)                                                # :559
+            source = downsample_uniform(to_map, 1.5 * c.voxel_size)                                                 # :560
         guess = pose_prediction(self.poses, self.times, stamp)                                                  # :563-564
         init = self._particles()                                                                                # :573
         if self.map.empty():                                                                                    # :585-593
-            self.map.add_pointcloud(cropped, guess)
+            if dev:
+                self.map.add_pointcloud_device(self._prep.cropped_ptr, self._prep.n_cropped, guess)
+            else:
+                self.map.add_pointcloud(cropped, guess)
             self.poses.append(guess); self.times.append(stamp)
             return ScanResult(stamp, guess, guess, preprocessing_s=time.perf_counter() - t0)
         if self._solver is None:
@@ -357,8 +445,11 @@ class RegistrationPipeline:
             ptr, M = self.map.get_map(guess, self.scan_max_range + 10.0)                                        # :577-578
             if M == 0:
                 ptr, M = self.map.get_map()                                                                     # :579-581
-            s.add_cloud_device_target(source, ptr, M, init)                                                     # :583
-            self.bytes_h2d += source.shape[0] * 24
+            if dev:
+                s.add_cloud_device(self._prep.source_ptr, self._prep.n_source, ptr, M, init)                    # :583
+            else:
+                s.add_cloud_device_target(source, ptr, M, init)                                                 # :583
+                self.bytes_h2d += source.shape[0] * 24
         else:
             target = self.map.get_map(guess, self.scan_max_range + 10.0)                                        # :577-578
             if target.shape[0] == 0:
@@ -374,9 +465,12 @@ class RegistrationPipeline:
         pose = guess @ correction_to_pose(corr)                                                                 # updater_, :37-46
         res = ScanResult(stamp, pose, guess, corr, s.get_distribution(), s.get_cov_matrix(), s.get_particles().reshape(-1),
                          s.get_particle_weight(), t1 - t0, 0.0, int(state))
-        self.map.add_pointcloud(to_map, pose)                                                                   # :627
-        if c.gpu_map:
-            self.bytes_h2d += to_map.shape[0] * 12
+        if dev:
+            self.map.add_pointcloud_device(self._prep.map_cloud_ptr, self._prep.n_map, pose)                    # :627
+        else:
+            self.map.add_pointcloud(to_map, pose)                                                               # :627
+            if c.gpu_map:
+                self.bytes_h2d += to_map.shape[0] * 12
         self.poses.append(pose); self.times.append(stamp)                                                       # :630
         res.align_s = time.perf_counter() - t1
         return res

@@ -168,6 +168,18 @@ class _SolverBase:
         self._check(self._L.svnicp_set_particles(self._h, init.ctypes.data_as(C.POINTER(C.c_double)), self._P),
                     "svnicp_set_particles")
 
+    def add_cloud_device(self, source_devptr: int, B: int, target_devptr: int, M: int, init_pose):
+        """add_cloud with both clouds already in HBM (float64 rows: DevicePreprocessor.source, DeviceVoxelHashMap.get_map):
+        two device-to-device copies, nothing crosses PCIe but the particle prior."""
+        self._check(self._L.svnicp_set_source(self._h, C.c_void_p(int(source_devptr)), int(B), 1), "svnicp_set_source")
+        self._check(self._L.svnicp_set_target(self._h, C.c_void_p(int(target_devptr)), int(M), 1), "svnicp_set_target")
+        self._check(self._L.svnicp_synchronize(self._h), "svnicp_synchronize")
+        self._B, self._M = int(B), int(M)
+        init = self._pose_arg(init_pose)
+        self._P = init.shape[1]
+        self._check(self._L.svnicp_set_particles(self._h, init.ctypes.data_as(C.POINTER(C.c_double)), self._P),
+                    "svnicp_set_particles")
+
     def set_initial_mean(self, pose):
         """SVGDICP::set_initial_mean(gtsam::Pose3) (include/core/SVGDICP.h:102-110).
         ``pose``: 4x4 homogeneous matrix, or a (R[3,3], t[3]) pair."""

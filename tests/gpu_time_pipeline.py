@@ -10,8 +10,9 @@ sc = pkg.scans
 scene = sc.make_scene(sc.SEED)
 n_pts = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-gpu_map = (sys.argv[3] if len(sys.argv) > 3 else "1") == "1"
-cfg = PipelineConfig(particle_count=P, gpu_map=gpu_map)
+mode = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # 0 host map, 1 device map, 2 device map + device pre-processing
+gpu_map = mode >= 1
+cfg = PipelineConfig(particle_count=P, gpu_map=gpu_map, gpu_prep=mode >= 2)
 pipe = RegistrationPipeline(cfg)
 pre, ali, tot = [], [], []
 for i in range(12):
@@ -23,5 +24,5 @@ for i in range(12):
     pre.append(r.preprocessing_s); ali.append(r.align_s); tot.append(t1 - t0)
     if i == 11:
         print("last pose x %.3f (truth %.3f)" % (r.pose[0, 3], 0.3 * i))
-print("scan of %d points, %d particles, gpu_map=%s: per scan median total %.2f ms = pre-processing+query+hand-over %.2f + align+insert %.2f; H2D %.1f MB in all" % (
-    n_pts, P, gpu_map, 1e3 * np.median(tot[3:]), 1e3 * np.median(pre[3:]), 1e3 * np.median(ali[3:]), pipe.bytes_h2d / 1e6))
+print("scan of %d points, %d particles, mode %s (0 host map, 1 device map, 2 + device pre-processing): per scan median total %.2f ms = pre-processing+query+hand-over %.2f + align+insert %.2f; H2D %.1f MB in all" % (
+    n_pts, P, mode, 1e3 * np.median(tot[3:]), 1e3 * np.median(pre[3:]), 1e3 * np.median(ali[3:]), pipe.bytes_h2d / 1e6))

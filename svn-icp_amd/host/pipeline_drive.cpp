@@ -2,7 +2,7 @@
 // dumps, per scan, what the pipeline handed to the solver and what it got back.  Used by tests/test_pipeline_gpu.py, which
 // replays the dumped solver inputs through the CPU oracle and through svn-icp_amd/pipeline.py.
 //   g++ -std=c++17 -I include -I svn-icp_amd/host pipeline_drive.cpp -L svn-icp_amd -lsvnicp_hip -o pipeline_drive
-//   pipeline_drive scans.bin out.bin P iterations knn voxel [particles.bin|-] [gpu_map 0|1]
+//   pipeline_drive scans.bin out.bin P iterations knn voxel [particles.bin|-] [gpu_map 0|1|2]   (2: device map + device pre-processing)
 // scans.bin : int32 n_scans, then per scan { f64 stamp, int32 n, n x 3 float32 }
 // particles : optional f64 [n_scans][6][P] (otherwise the built-in uniform prior sampler)
 // out.bin   : per scan { int32 aligned, f64 pose[12], guess[12], corr[6], var[6], cov[36], int64 B, M, f64 src[3B], tgt[3M], init[6P] }
@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
   cfg.min_range = 1.0; cfg.max_range = 80.0; cfg.map_range = 100.0; cfg.map_voxel_max_points = 20;
   FILE* fp = (argc > 7 && argv[7][0] != '-') ? fopen(argv[7], "rb") : nullptr;
   cfg.gpu_map = argc > 8 && atoi(argv[8]) != 0;
+  cfg.gpu_prep = argc > 8 && atoi(argv[8]) >= 2;
   try {
     svnicp::RegistrationPipeline pipe(cfg);
     svnicp::Tap tap;

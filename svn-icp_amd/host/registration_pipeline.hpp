@@ -233,6 +233,9 @@ class DeviceVoxelMap {
   void AddPointCloud(const Cloud& cloud, const Pose3& pose) {
     chk(svnicp_map_add_cloud(m_, cloud.empty() ? nullptr : &cloud[0][0], (int64_t)cloud.size(), SVNICP_MEM_HOST, pose.R.data(), pose.t.data()));
   }
+  void AddPointCloudDevice(const float* dev_xyz, int64_t n, const Pose3& pose) {   // float32 rows already in HBM (DevicePrep)
+    chk(svnicp_map_add_cloud(m_, dev_xyz, n, SVNICP_MEM_DEVICE, pose.R.data(), pose.t.data()));
+  }
   // -> number of points; the rows are at points_devptr()
   int64_t GetMap(const Pose3& pose, double max_range) { int64_t n = 0; chk(svnicp_map_query(m_, pose.t.data(), max_range, &n)); return n; }
   int64_t GetMap() { int64_t n = 0; chk(svnicp_map_query(m_, nullptr, -1.0, &n)); return n; }
@@ -248,6 +251,34 @@ class DeviceVoxelMap {
  private:
   void chk(int rc) { if (rc != 0) throw std::runtime_error(svnicp_map_last_error(m_)); }
   svnicp_map* m_ = nullptr;
+};
+
+// crop_pointcloud + the two uniform samplings on the device (svnicp_prep_*, csrc/scan_prep.hip): the raw scan is uploaded
+// once; the cropped cloud, the map cloud (float32) and the source cloud (float64 rows) stay in HBM
+class DevicePrep {
+ public:
+  explicit DevicePrep(int device = 0) { if (svnicp_prep_create(device, &p_) != 0) throw std::runtime_error(svnicp_prep_last_error(nullptr)); }
+  ~DevicePrep() { svnicp_prep_destroy(p_); }
+  DevicePrep(const DevicePrep&) = delete;
+  DevicePrep& operator=(const DevicePrep&) = delete;
+  void scan(const Cloud& points, double min_range, double max_range, double voxel_size, double* scan_max_range) {
+    if (svnicp_prep_scan(p_, points.empty() ? nullptr : &points[0][0], (int64_t)points.size(), SVNICP_MEM_HOST, min_range, max_range, voxel_size,
+                         scan_max_range, &n_cropped, &n_map, &n_source) != 0)
+      throw std::runtime_error(svnicp_prep_last_error(p_));
+  }
+  const float* cropped() { return svnicp_prep_cropped_devptr(p_); }
+  const float* map_cloud() { return svnicp_prep_map_cloud_devptr(p_); }
+  const double* source() { return svnicp_prep_source_devptr(p_); }
+  std::vector<double> download_source() {   // test tap
+    std::vector<float> f((size_t)3 * n_source);
+    int64_t n = 0;
+    if (n_source && svnicp_prep_download(p_, 2, f.data(), n_source, &n) != 0) throw std::runtime_error(svnicp_prep_last_error(p_));
+    return std::vector<double>(f.begin(), f.end());
+  }
+  int64_t n_cropped = 0, n_map = 0, n_source = 0;
+
+ private:
+  svnicp_prep* p_ = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------ prediction
@@ -276,6 +307,7 @@ struct PipelineConfig {  // field names follow the node's parameters (OdometryPi
   uint64_t seed = 0;
   int device = 0;
   bool gpu_map = false;  // keep the local map in HBM (DeviceVoxelMap): the target never crosses PCIe
+  bool gpu_prep = false; // with gpu_map: crop and both uniform samplings on the device (DevicePrep): the raw scan is uploaded, no host pass over the points
 };
 
 struct ScanResult {
@@ -301,6 +333,7 @@ class RegistrationPipeline {
   explicit RegistrationPipeline(const PipelineConfig& cfg)
       : cfg_(cfg), map_(cfg.map_voxel_size, cfg.map_range, cfg.map_voxel_max_points), rng_(cfg.seed * 0x9e3779b97f4a7c15ull + 0x2545f4914f6cdd1dull) {
     if (cfg.gpu_map) dmap_ = std::make_unique<DeviceVoxelMap>(cfg.map_voxel_size, cfg.map_range, cfg.map_voxel_max_points, cfg.device);
+    if (cfg.gpu_map && cfg.gpu_prep) dprep_ = std::make_unique<DevicePrep>(cfg.device);
   }
 
   // replaces the built-in uniform prior sampler (svnicp::initialize_particles, ICPUtils.cpp:45-58): fills [6][P] row-major
@@ -315,26 +348,40 @@ class RegistrationPipeline {
   ScanResult process_scan(const Cloud& points, double stamp) {
     ScanResult res;
     res.stamp = stamp;
-    const Cloud cropped = crop_pointcloud(points, cfg_.min_range, cfg_.max_range, &scan_max_range_);  // :556
-    const Cloud to_map = downsample_uniform(cropped, 0.5 * cfg_.voxel_size);                           // :559
-    const Cloud source = downsample_uniform(to_map, 1.5 * cfg_.voxel_size);                            // :560
+    Cloud cropped, to_map, source;
+    if (dprep_) {
+      dprep_->scan(points, cfg_.min_range, cfg_.max_range, cfg_.voxel_size, &scan_max_range_);         // :556-560 on the device
+      bytes_h2d_ += points.size() * 12;
+    } else {
+      cropped = crop_pointcloud(points, cfg_.min_range, cfg_.max_range, &scan_max_range_);             // :556
+      to_map = downsample_uniform(cropped, 0.5 * cfg_.voxel_size);                                     // :559
+      source = downsample_uniform(to_map, 1.5 * cfg_.voxel_size);                                      // :560
+    }
     const Pose3 guess = pose_prediction(poses_, times_, stamp);                                        // :563-564
     std::vector<double> init = sample_particles();                                                     // :573
     res.initial_guess = guess;
     if (dmap_ ? dmap_->Empty() : map_.Empty()) {                                                       // :585-593
-      if (dmap_) { dmap_->AddPointCloud(cropped, guess); bytes_h2d_ += cropped.size() * 12; } else map_.AddPointCloud(cropped, guess);
+      if (dprep_) dmap_->AddPointCloudDevice(dprep_->cropped(), dprep_->n_cropped, guess);
+      else if (dmap_) { dmap_->AddPointCloud(cropped, guess); bytes_h2d_ += cropped.size() * 12; }
+      else map_.AddPointCloud(cropped, guess);
       poses_.push_back(guess); times_.push_back(stamp);
       res.pose = guess;
       return res;
     }
-    const std::vector<double> src64 = widen(source);                                                   // ICPUtils.cpp:27-43
+    std::vector<double> src64;
+    if (!dprep_) src64 = widen(source);                                                                // ICPUtils.cpp:27-43
     if (!solver_) solver_ = std::make_unique<SVNICP>(cfg_.solver, init, ParticleWeightOpt{}, cfg_.device);
     std::vector<double> tgt64;
     if (dmap_) {
       int64_t M = dmap_->GetMap(guess, scan_max_range_ + 10.0);                                        // :577-578
       if (M == 0) M = dmap_->GetMap();                                                                 // :579-581
-      solver_->add_cloud_device_target(src64.data(), (int64_t)source.size(), dmap_->points_devptr(), M, init.data(), cfg_.particle_count);
-      bytes_h2d_ += src64.size() * 8;
+      if (dprep_) {
+        solver_->add_cloud_device(dprep_->source(), dprep_->n_source, dmap_->points_devptr(), M, init.data(), cfg_.particle_count);
+        if (tap_) src64 = dprep_->download_source();
+      } else {
+        solver_->add_cloud_device_target(src64.data(), (int64_t)source.size(), dmap_->points_devptr(), M, init.data(), cfg_.particle_count);
+        bytes_h2d_ += src64.size() * 8;
+      }
       if (tap_) tgt64 = dmap_->download();
     } else {
       Cloud target = map_.GetMap(guess, scan_max_range_ + 10.0);                                       // :577-578
@@ -354,7 +401,9 @@ class RegistrationPipeline {
     res.particles = solver_->get_particles();
     res.weights = solver_->get_particle_weight();
     res.pose = guess * correction_to_pose(res.correction);                                             // updater_, :37-46
-    if (dmap_) { dmap_->AddPointCloud(to_map, res.pose); bytes_h2d_ += to_map.size() * 12; } else map_.AddPointCloud(to_map, res.pose);  // :630
+    if (dprep_) dmap_->AddPointCloudDevice(dprep_->map_cloud(), dprep_->n_map, res.pose);              // :630
+    else if (dmap_) { dmap_->AddPointCloud(to_map, res.pose); bytes_h2d_ += to_map.size() * 12; }
+    else map_.AddPointCloud(to_map, res.pose);
     poses_.push_back(res.pose); times_.push_back(stamp);
     return res;
   }
@@ -393,6 +442,7 @@ class RegistrationPipeline {
   Tap* tap_ = nullptr;
   std::unique_ptr<SVNICP> solver_;
   std::unique_ptr<DeviceVoxelMap> dmap_;
+  std::unique_ptr<DevicePrep> dprep_;
   size_t bytes_h2d_ = 0;
 };
 

@@ -64,6 +64,14 @@ class SVGDICP {
     chk(svnicp_set_particles(h_, init_pose6xP, P));
     P_ = P;
   }
+  // add_cloud with both clouds already in HBM (float64 rows): two device-to-device copies
+  void add_cloud_device(const double* source_dev_xyz, int64_t B, const double* target_dev_xyz, int64_t M, const double* init_pose6xP, int P) {
+    chk(svnicp_set_source(h_, source_dev_xyz, B, SVNICP_MEM_DEVICE));
+    chk(svnicp_set_target(h_, target_dev_xyz, M, SVNICP_MEM_DEVICE));
+    chk(svnicp_synchronize(h_));
+    chk(svnicp_set_particles(h_, init_pose6xP, P));
+    P_ = P;
+  }
   // set_initial_mean(gtsam::Pose3) — SVGDICP.h:102-110
   void set_initial_mean(const double R_rowmajor[9], const double t[3]) { chk(svnicp_set_initial_mean(h_, R_rowmajor, t)); }
   virtual SteinICPState stein_align() {  // SVNICP.cpp:41-114 / SVGDICP.cpp:66-140

@@ -109,7 +109,14 @@ def test_cpp_registration_pipeline_against_oracle_and_python(hip, orc, tmp_path)
     for a_, b_ in zip(recs, parse(tmp_path / "out_gpu.bin")):
         assert np.array_equal(a_["tgt"], b_["tgt"]) and np.array_equal(a_["src"], b_["src"])
         assert np.array_equal(a_["pose"], b_["pose"]) and np.array_equal(a_["cov"], b_["cov"])
-    print(r.stdout.splitlines()[-1]); print(r2.stdout.splitlines()[-1])
+    # ... and with crop + both uniform samplings on the device as well (DevicePrep): the same source rows too
+    r3 = subprocess.run([exe, str(tmp_path / "scans.bin"), str(tmp_path / "out_gpu2.bin"), str(P), str(I), str(K), str(voxel),
+                         str(tmp_path / "particles.bin"), "2"], capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    for a_, b_ in zip(recs, parse(tmp_path / "out_gpu2.bin")):
+        assert np.array_equal(a_["tgt"], b_["tgt"]) and np.array_equal(a_["src"], b_["src"])
+        assert np.array_equal(a_["pose"], b_["pose"]) and np.array_equal(a_["cov"], b_["cov"])
+    print(r.stdout.splitlines()[-1]); print(r2.stdout.splitlines()[-1]); print(r3.stdout.splitlines()[-1])
 
     def mat(p12):
         T = np.eye(4); T[:3, :3] = p12[:9].reshape(3, 3); T[:3, 3] = p12[9:]

@@ -708,7 +708,7 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
       unsigned long long h[8];
       HIPCHK(c, hipStreamSynchronize(c->stream));
       HIPCHK(c, hipMemcpy(h, dbg_upd, sizeof(h), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[svnicp] k_particle_update thread-0 cycles (summed over launches so far): prepare %llu median %llu direction %llu pose %llu tail %llu\n", h[0], h[1], h[2], h[3], h[4]);
+      fprintf(stderr, "[svnicp] Stein step thread-0 cycles (summed over launches so far; fused kernel: prepare / median / direction / pose / tail; k_upd_front workgroup 0: state / histogram / bin scan / collect / rank): %llu %llu %llu %llu %llu\n", h[0], h[1], h[2], h[3], h[4]);
     }
   }
   u.svgd = 0;

@@ -789,6 +789,13 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
     }
     return;
   }
+  unsigned long long tdbg = a.dbg ? __builtin_readcyclecounter() : 0ull;
+  auto stamp = [&](int i) {   // debug option: thread-0 cycles per phase of the median workgroup
+    if (!a.dbg || tid != 0) return;
+    const unsigned long long now = __builtin_readcyclecounter();
+    a.dbg[i] += now - tdbg;
+    tdbg = now;
+  };
   for (int e = tid; e < HB_NB; e += UT) lh[e] = 0u;
   if (tid == 0) { sh_cnt = 0u; sh_nan = 0; sh_bin = 0; sh_rank = 0; }
   for (int p = tid; p < P; p += UT) {
@@ -806,30 +813,43 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
     }
   }
   __syncthreads();
+  stamp(0);
 
-  // pass 1 over the pairs: log-binned histogram
+  // pass 1 over the pairs: log-binned histogram.  The matrix of pair distances is symmetric bit for bit ((a-b)² == (b-a)²)
+  // with zeros on the diagonal: only the pairs i < j are binned, each with weight 2, and the P diagonal zeros go in with
+  // one update — half the distance evaluations and half the LDS atomics (which pile up on a few bins: 46 % of this
+  // workgroup's time went into this pass)
   const int n = P * P;
   bool nan = false;
-  const int di = UT / P, dj = UT - di * P;  // pair index advance per step of UT entries
-  double keys[KREG];                         // this thread's pair distances (P <= 128: KREG * UT >= P²)
+  // the pairs i < j as a rectangle of Pe/2 rows x (Pe - 1) columns (Pe = P rounded up to even): row a holds (a, c + 1) for
+  // c >= a and (Pe - 1 - a, Pe - 1 - c) for c < a — every unordered pair exactly once, so all lanes work in every step
+  constexpr int KH = (KREG + 1) / 2 + 1;     // steps per thread: KH * UT >= (Pe / 2)(Pe - 1) for P <= 128
+  const int Pe = P + (P & 1), W = Pe - 1, npair = (Pe / 2) * W;
+  const int di = UT / W, dj = UT - di * W;   // pair index advance per step of UT entries
+  double keys[KH];                           // this thread's pair distances with i < j
+  const int bin0 = key_bin(0ull);            // bin of +0.0
+  if (tid == 0) atomicAdd(&lh[bin0], (unsigned int)P);
+  for (int p = tid; p < P; p += UT) { const double sq = pair_sq(lx, p, p); if (sq != sq) nan = true; }   // a non-finite particle: inf - inf on the diagonal
   {
-    int i = tid / P, j = tid - i * P;
+    int ra = tid / W, c = tid - ra * W;
 #pragma unroll
-    for (int k = 0; k < KREG; ++k) {
+    for (int k = 0; k < KH; ++k) {
       const int e = tid + k * UT;
       keys[k] = __builtin_huge_val();
-      if (e < n) {
+      const int i = c >= ra ? ra : Pe - 1 - ra, j = c >= ra ? c + 1 : Pe - 1 - c;
+      if (e < npair && j < P) {              // (j < P also implies i < P; only an odd P has a virtual last index)
         const double sq = pair_sq(lx, i, j);
-        keys[k] = sq;
         if (sq != sq) nan = true;
-        atomicAdd(&lh[key_bin((unsigned long long)__double_as_longlong(sq))], 1u);
+        keys[k] = sq;
+        atomicAdd(&lh[key_bin((unsigned long long)__double_as_longlong(sq))], 2u);
       }
-      j += dj; i += di;
-      if (j >= P) { j -= P; ++i; }
+      c += dj; ra += di;
+      if (c >= W) { c -= W; ++ra; }
     }
   }
   if (nan) sh_nan = 1;
   __syncthreads();
+  stamp(1);
   {  // bin of the lower median: contiguous chunk of bins per thread, block-wide exclusive scan of the chunk sums
     constexpr int CH = HB_NB / UT;
     unsigned int c[CH], tot = 0;
@@ -854,21 +874,25 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
     }
   }
   __syncthreads();
-  // pass 2: the keys of that bin
+  stamp(2);
+  // pass 2: the keys of that bin (one copy of each i < j pair)
   const int bstar = sh_bin;
 #pragma unroll
-  for (int k = 0; k < KREG; ++k) {
-    if (tid + k * UT < n && key_bin((unsigned long long)__double_as_longlong(keys[k])) == bstar) {
+  for (int k = 0; k < KH; ++k) {
+    if (keys[k] < __builtin_huge_val() && key_bin((unsigned long long)__double_as_longlong(keys[k])) == bstar) {
       const unsigned int pos = atomicAdd(&sh_cnt, 1u);
       if (pos < FRONT_BUF) lbuf[pos] = keys[k];
     }
   }
   __syncthreads();
+  stamp(3);
   const int m = (int)sh_cnt;
   double med;
   if (m <= FRONT_BUF) {
-    // exact rank inside the bin by counting: the key with #less <= r < #less + #equal is the median
+    // exact rank inside the bin by counting, every collected key standing for two matrix entries and the diagonal for P
+    // zeros: the value with #less <= r < #less + #equal is the median
     const int r = sh_rank;
+    const bool zin = bstar == bin0;          // the diagonal's zeros are in this bin
     for (int e = m + tid; e < ((m + 7) & ~7); e += UT) lbuf[e] = __builtin_huge_val();  // pad to the unroll width
     __syncthreads();
     for (int e = tid; e < m; e += UT) {
@@ -881,7 +905,13 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) { lt += u[t] < v ? 1 : 0; eq += u[t] == v ? 1 : 0; }
       }
-      if (lt <= r && r < lt + eq) sel.h = v;  // every matching thread writes the same value
+      const int LT = 2 * lt + ((zin && 0.0 < v) ? P : 0), EQ = 2 * eq + ((zin && v == 0.0) ? P : 0);
+      if (LT <= r && r < LT + EQ) sel.h = v;  // every matching thread writes the same value
+    }
+    if (zin && tid == 0) {                    // the median may be one of the diagonal's zeros
+      int eq0 = 0;
+      for (int j = 0; j < m; ++j) eq0 += lbuf[j] == 0.0 ? 1 : 0;
+      if (r < 2 * eq0 + P) sel.h = 0.0;
     }
     __syncthreads();
     med = sel.h;
@@ -892,6 +922,7 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
     med = sel.h * log((double)(P + 1));  // rbf_bandwidth returns h, undo its scaling
     __syncthreads();
   }
+  stamp(4);
   if (tid == 0) a.uctl[UCTL_H] = (sh_nan ? __builtin_nan("") : med) / log((double)(P + 1));  // SVNICP.cpp:262
 }
 

@@ -366,6 +366,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "debug") ok = num(0, 1, &t.debug);
   else if (k == "scan_split") ok = num(0, 16, &t.scan_split);
   else if (k == "group_stride") ok = num(0, 1 << 30, &t.group_stride);
+  else if (k == "accum_min_steps") ok = num(0, 1 << 20, &t.accum_min_steps);
   else if (k == "correspondence") { if (v == "fast") t.full_corr = 0; else if (v == "full") t.full_corr = 1; else ok = false; }
   else return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: unknown option '" + k + "'");
   if (!ok) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: bad value '" + v + "' for option '" + k + "'");

@@ -148,6 +148,7 @@ struct Tuning {
   int fused_update_max_p = 128;  // above this the Stein step runs as workgroup-parallel kernels
   int wgpcu_search = 0, wgpcu_accum = 0;   // workgroups per CU the stage-B grids are sized for (0 = automatic)
   int tp = 0;                    // fused stage-B variants: source points per LDS tile (0 = automatic)
+  int accum_min_steps = 0;       // least wave steps per accumulate workgroup (0 = default 4)
   int group_stride = 0;          // stage A scan: group order stride (0 = default, 1 = natural order)
   int scan_split = 0;            // stage A scan: waves per 64-query workgroup, 4 or 8 (0 = default)
   int debug = 0;                 // print plans and per-phase cycle counters to stderr

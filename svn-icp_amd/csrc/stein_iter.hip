@@ -463,10 +463,13 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
   pl.RS = (3 * K) | 1;
   if (f32 == 3) {  // split variant: no LDS tiles; each kernel gets one resident round of workgroups (search: two)
     const int64_t steps = (B + pass - 1) / pass;
-    auto size_grid = [&](int wg_per_cu, int* gx, int* ppb) {
+    auto size_grid = [&](int wg_per_cu, int* gx, int* ppb, int min_steps) {
       int64_t want = (int64_t)num_cus * wg_per_cu / (pl.grid_y > 0 ? pl.grid_y : 1);
       if (want < 1) want = 1;
-      const int64_t g = steps < want ? steps : want;
+      int64_t g = steps < want ? steps : want;
+      // small clouds (the scan-to-map loop hands over ~1000 source points): a workgroup gets at least min_steps wave steps —
+      // each accumulate workgroup writes 22 sums per particle that k_reduce_partials must read back
+      if (min_steps > 1 && steps / g < min_steps) { g = steps / min_steps; if (g < 1) g = 1; }
       const int64_t spb = (steps + g - 1) / g;     // wave steps per workgroup
       *ppb = (int)(spb * pass);
       *gx = (int)((B + *ppb - 1) / *ppb);
@@ -483,8 +486,8 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
                                          // the accumulate kernel pays per workgroup in k_reduce_partials: 4 per CU
       if (occ_a > 4) occ_a = 4;
     }
-    size_grid(occ_a, &pl.grid_x, &pl.pts_per_block);
-    size_grid(occ_s, &pl.sgrid_x, &pl.spts_per_block);
+    size_grid(occ_a, &pl.grid_x, &pl.pts_per_block, tune.accum_min_steps > 0 ? tune.accum_min_steps : 4);
+    size_grid(occ_s, &pl.sgrid_x, &pl.spts_per_block, 1);
     pl.TP = pass; pl.n_tiles = 0; pl.tiles_per_block = 0;
     return pl;
   }

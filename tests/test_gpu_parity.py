@@ -340,6 +340,30 @@ def test_map_frame_coordinates_far_from_the_origin(hip, orc, P, B, M, K):
     _compare(s, o, tro, P)
 
 
+@pytest.mark.parametrize("P,same", [(6, 5), (6, 3), (9, 9), (33, 20), (128, 100)])
+def test_bandwidth_median_with_coincident_particles(hip, orc, P, same):
+    """`same` of the P particles start at exactly the same pose: their pair distances are exact zeros, as is the diagonal.
+    The lower median of the P x P matrix (SVNICP.cpp:257-262) is then zero or the smallest positive distance depending on
+    the count — the symmetric pair pass of k_upd_front (pairs i < j with weight 2, the diagonal as P zeros) must land on
+    the same entry as the oracle's full sort."""
+    src, tgt = hip.scans.random_clouds(400, 1500, seed=P + same)
+    init = hip.scans.make_particles(P, seed=P) * 0.3
+    init[:, :same] = init[:, :1]
+    cfg = dict(iterations=1, lr=1.0, max_dist=1.0, check_early_stop=False, convergence_threshold=1e-5, knn_count=10,
+               svn_full_grad=False)
+    o = orc.Solver(init, **cfg)
+    o.add_cloud(src, tgt, init)
+    tro = o.enable_trace(); o.stein_align()
+    s = _hip_solver(hip, init, **cfg)
+    s.add_cloud(src, tgt, init)
+    s.stein_align()
+    h_gpu, h_orc = s.get_trace()["h"][0], tro["h"][0]
+    assert (h_gpu == 0.0) == (h_orc == 0.0)
+    assert h_gpu == h_orc or abs(h_gpu - h_orc) <= 1e-12 * abs(h_orc)
+    zeros = same * same + (P - same)
+    assert (h_orc == 0.0) == (zeros > (P * P - 1) // 2)
+
+
 def test_exact_ties_lowest_index_wins(hip, orc):
     """Integer-grid clouds: distances are exact and massively tied in stage A and stage B; the HIP
     path must break every tie like the reference CPU KNN (lowest index / first position)."""

@@ -140,8 +140,7 @@ class _SolverBase:
             self._keep = (src, tgt)
             B, M = src.shape[0], tgt.shape[0]
             rc = self._L.svnicp_set_clouds(self._h, C.c_void_p(src.data_ptr()), B, C.c_void_p(tgt.data_ptr()), M, 1)
-            self._check(rc, "svnicp_set_clouds")
-            self._check(self._L.svnicp_synchronize(self._h), "svnicp_synchronize")
+            self._check(rc, "svnicp_set_clouds")      # the copies are complete when svnicp_set_particles below returns (it waits for the stream)
         else:
             src = np.ascontiguousarray(np.asarray(new_cloud, np.float64).reshape(-1, 3))
             tgt = np.ascontiguousarray(np.asarray(target, np.float64).reshape(-1, 3))
@@ -161,7 +160,6 @@ class _SolverBase:
         src = np.ascontiguousarray(np.asarray(new_cloud, np.float64).reshape(-1, 3))
         self._check(self._L.svnicp_set_source(self._h, src.ctypes.data_as(C.c_void_p), src.shape[0], 0), "svnicp_set_source")
         self._check(self._L.svnicp_set_target(self._h, C.c_void_p(int(target_devptr)), int(M), 1), "svnicp_set_target")
-        self._check(self._L.svnicp_synchronize(self._h), "svnicp_synchronize")
         self._B, self._M = src.shape[0], int(M)
         init = self._pose_arg(init_pose)
         self._P = init.shape[1]
@@ -173,7 +171,6 @@ class _SolverBase:
         two device-to-device copies, nothing crosses PCIe but the particle prior."""
         self._check(self._L.svnicp_set_source(self._h, C.c_void_p(int(source_devptr)), int(B), 1), "svnicp_set_source")
         self._check(self._L.svnicp_set_target(self._h, C.c_void_p(int(target_devptr)), int(M), 1), "svnicp_set_target")
-        self._check(self._L.svnicp_synchronize(self._h), "svnicp_synchronize")
         self._B, self._M = int(B), int(M)
         init = self._pose_arg(init_pose)
         self._P = init.shape[1]

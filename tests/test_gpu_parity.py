@@ -340,11 +340,12 @@ def test_map_frame_coordinates_far_from_the_origin(hip, orc, P, B, M, K):
     _compare(s, o, tro, P)
 
 
-@pytest.mark.parametrize("P,same", [(6, 5), (6, 3), (9, 9), (33, 20), (128, 100)])
+@pytest.mark.parametrize("P,same", [(6, 5), (6, 3), (9, 9), (33, 20), (128, 100), (200, 150), (301, 10), (257, 257)])
 def test_bandwidth_median_with_coincident_particles(hip, orc, P, same):
     """`same` of the P particles start at exactly the same pose: their pair distances are exact zeros, as is the diagonal.
     The lower median of the P x P matrix (SVNICP.cpp:257-262) is then zero or the smallest positive distance depending on
-    the count — the symmetric pair pass of k_upd_front (pairs i < j with weight 2, the diagonal as P zeros) must land on
+    the count — the symmetric pair pass of k_upd_front (pairs i < j with weight 2, the diagonal as P zeros) and the
+    histogram chain above 128 particles must land on
     the same entry as the oracle's full sort."""
     src, tgt = hip.scans.random_clouds(400, 1500, seed=P + same)
     init = hip.scans.make_particles(P, seed=P) * 0.3

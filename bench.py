@@ -10,9 +10,11 @@ resident in HBM before the timed region starts.
 
 N = 1 runs the headline configuration C3 (128 particles × 131 072 source / 262 144 target points,
 K = 100, I = 20, float64); `value` = registrations/s.
-N > 1 runs BASELINE configuration C4 — 512 particles FIXED, sharded 512/N per GPU, one all-gather of
-176 B per particle per iteration over RCCL — so `value` is the raw registrations/s of the same
-512-particle registration at every N (`"scaling": "strong"`).  Next to it the line carries
+N > 1 runs BASELINE configuration C4 — 512 particles FIXED — with the SOURCE ROWS sharded B/N per GPU
+(`--split rows`, the default: every GPU searches and accumulates its rows for all particles, one all-gather
+of N × P × 176 B partial sums per iteration over RCCL; `--split particles` is the 512/N-particles-per-GPU
+layout) — so `value` is the raw registrations/s of the same 512-particle registration at every N
+(`"scaling": "strong"`).  Next to it the line carries
 `speedup_vs_1gpu` (rank 0 times the unsharded 512-particle registration on its own GPU in the same
 invocation, outside the timed region) and a `weak_scaling` record (C3 clouds, 128 particles per GPU,
 raw registrations/s).  The N = 1 line carries the one-GPU C4 rate as `c4_one_gpu` so that the
@@ -59,6 +61,8 @@ def parse():
                     help="source points of the CPU-baseline sample, evenly spaced over the scan (-1 = the whole source, 0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent brackets")
     ap.add_argument("--mode", default="svn", choices=("svn", "svgd"), help="svn (headline) | svgd (first-order sibling, N = 1)")
+    ap.add_argument("--split", default="rows", choices=("rows", "particles"),
+                    help="N > 1: what is cut across the GPUs — source rows (default: nothing of size [B] replicated) or particles")
     return ap.parse_args()
 
 
@@ -135,42 +139,36 @@ def main():
     if world == 1:
         solver = (pkg.SVGDICP(prm, init, device=local_rank) if svgd else
                   pkg.SVNICP(prm, init, pkg.ParticleWeightOpt(), device=local_rank))
-        if not a.no_profile:
-            solver.set_profile(True)
         if a.correspondence == "full":
             solver.set_option("correspondence", "full")
     else:
         from svnicp_amd.sharded import ShardedSVNICP
-        solver = ShardedSVNICP(prm, init, device_index=local_rank)
+        solver = ShardedSVNICP(prm, init, device_index=local_rank, split=a.split)
     step = make_step(solver, init)
 
-    kernel_ms = {}
     for i in range(a.warmup):
         step()
-        if world == 1 and not a.no_profile and i == a.warmup - 1:
-            # per-class detail from the last (untimed) warmup step with every launch bracketed; the timed steps bracket
-            # only the kernels the roofline block reports, because each event pair costs ~5 us of stream time
-            for k, (ms, n) in solver.get_kernel_ms().items():
-                kernel_ms[k] = [ms * a.steps, n * a.steps]   # scaled to the timed step count (detail block only)
-    timed_classes = ("k_stein_search", "k_stein_accumulate", "stage_a_knn")
-    if world == 1 and not a.no_profile and a.warmup > 0:
-        solver.set_profile(True, timed_classes)
-        for k in timed_classes:
-            kernel_ms[k] = [0.0, 0]
     last = {}
 
     def timed_step():
         st, mean, cov = step()
         last["mean"] = mean
-        if world == 1 and not a.no_profile:
+    # the timed region: exactly K steps of the product as a caller runs it — no event brackets, no profiling hooks
+    el = time_steps(timed_step, a.steps, world, dist, torch, dev)
+    mean = last["mean"]
+
+    # roofline region: the SAME K steps once more, every kernel launch bracketed by hipEvents on the library's stream
+    # (svnicp_set_profile; ~5 us of stream time per bracket, which is why this pass is not the one `value` comes from)
+    kernel_ms = {}
+    if world == 1 and not a.no_profile:
+        solver.set_profile(True)
+        for _ in range(a.steps):
+            step()
             for k, (ms, n) in solver.get_kernel_ms().items():
-                if a.warmup > 0 and k not in timed_classes:
-                    continue
                 acc = kernel_ms.setdefault(k, [0.0, 0])
                 acc[0] += ms
                 acc[1] += n
-    el = time_steps(timed_step, a.steps, world, dist, torch, dev)
-    mean = last["mean"]
+        solver.set_profile(False)
 
     pose_err = np.abs(mean - pair.true_pose)
     mode_name = "SVGD-ICP (Adam, lr 0.01)" if svgd else "SVN-ICP"
@@ -183,7 +181,7 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": 1e3 * el / a.steps,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong" if world > 1 else None,   # one GPU: there is nothing to scale
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo — not a measurement)",
@@ -191,9 +189,12 @@ def main():
                                f"max_dist=1.0, lr={prm.lr}, SVNFullGrad={bool(a.full_grad)}, correspondence={a.correspondence}, early stop off; synthetic 64-beam "
                                f"scans (seed {scans.SEED})",
                    "particles": P, "source_points": B, "target_points": M, "knn_count": K, "iterations": I,
-                   "parallelism": "single GPU" if world == 1 else f"{P} particles fixed, sharded {P // world}/GPU; stage A "
-                                  f"sharded by source rows; one all-gather of 176 B/particle/iteration (RCCL, world size "
-                                  f"{dist.get_world_size()} as reported by the process group)"},
+                   "parallelism": "single GPU" if world == 1 else (
+                       (f"source rows sharded {B // world}/GPU, all {P} particles on every GPU, candidate search and table per shard; "
+                        f"per iteration one all-gather of {world} x {P} x 176 B partial sums, added in rank order on every GPU"
+                        if a.split == "rows" else
+                        f"{P} particles fixed, sharded {P // world}/GPU; stage A sharded by source rows; one all-gather of 176 "
+                        f"B/particle/iteration") + f" (RCCL, world size {dist.get_world_size()} as reported by the process group)")},
         "particle_registrations_per_s": P * a.steps / el,
         "pose_error_vs_planted": {"trans_m": float(pose_err[:3].max()), "rot_rad": float(pose_err[3:].max())},
     }
@@ -216,7 +217,7 @@ def main():
             pw = scans.make_pair(cfgw["B"], cfgw["M"])
             src_d = torch.from_numpy(pw.source).to(dev); tgt_d = torch.from_numpy(pw.target).to(dev)
         initw = scans.make_particles(Pw)
-        sw = ShardedSVNICP(prm, initw, device_index=local_rank)
+        sw = ShardedSVNICP(prm, initw, device_index=local_rank, split=a.split)
         wstep = make_step(sw, initw)
         wstep()
         elw = time_steps(wstep, nside, world, dist, torch, dev)

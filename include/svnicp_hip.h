@@ -139,6 +139,20 @@ int svnicp_set_option(svnicp_ctx *ctx, const char *name, const char *value);
  *   svnicp_iter_accumulate -> [host all-gathers svnicp_sums_devptr, 22 doubles per particle] ->
  *   svnicp_iter_update ; finally svnicp_finish.  svnicp_align == all of it with one shard. */
 int svnicp_set_shard(svnicp_ctx *ctx, int p_lo, int p_hi);
+/* ---- the other split: SOURCE ROWS sharded across ranks (the one bench.py --gpus N uses) ---------------------------
+ * Rank r is given only ITS rows of the source scan (svnicp_set_source / svnicp_set_clouds with the row slice) and the
+ * whole target; it runs stage A, the candidate table and the per-iteration search + accumulation on those rows for ALL
+ * particles, so nothing of size [B] is replicated or gathered.  Its 22 sums per particle are a partial record; the ranks
+ * exchange them (all-gather of row_world x P x 22 doubles into svnicp_rank_sums_devptr, slot = row_rank) and
+ * svnicp_iter_update adds the records in rank order before the Stein step — every rank the same values in the same
+ * order, so the replicas stay bit-identical.  total_source_points = the whole scan's B (SVGD mode scales by it,
+ * SVGDICP.cpp:58).  row_world = 1 returns to the unsharded behaviour.  May be combined with svnicp_set_shard
+ * (2-D split): the record slot [row_rank][p_lo, p_hi) is then this rank's contribution.
+ * Sequence: svnicp_set_row_shard -> svnicp_align_begin -> svnicp_stage_candidates(0, rows) ->
+ * svnicp_build_candidate_table -> per iteration { svnicp_iter_accumulate -> [all-gather] -> svnicp_iter_update } ->
+ * svnicp_finish. */
+int svnicp_set_row_shard(svnicp_ctx *ctx, int row_rank, int row_world, int64_t total_source_points);
+void *svnicp_rank_sums_devptr(svnicp_ctx *ctx);  /* double [row_world][P][SVNICP_NSUMS]; NULL unless row_world > 1 */
 int svnicp_align_begin(svnicp_ctx *ctx);
 int svnicp_stage_candidates(svnicp_ctx *ctx, int64_t b_lo, int64_t b_hi);
 int svnicp_build_candidate_table(svnicp_ctx *ctx);
@@ -198,6 +212,9 @@ int svnicp_get_knn_survivors(svnicp_ctx *ctx, int32_t *outB);
 /* wave steps of the last align whose float32 nearest-candidate search was not decisive and were
  * redone in float64 (-1 when the float64 kernel ran alone) */
 int svnicp_get_ambiguous_steps(svnicp_ctx *ctx, int *out);
+/* (source point, particle) pairs of the last align that the bf16 matrix-pipe search could not certify and handed to its
+ * exact float64 pass (-1 when another search kernel ran) */
+int svnicp_get_ambiguous_pairs(svnicp_ctx *ctx, int64_t *out);
 /* bench hook: when on, every kernel launch of an align is bracketed by hipEvents on the
  * context's stream; svnicp_get_kernel_ms then returns the summed milliseconds and launch counts
  * per kernel class of the LAST align, SVNICP_KERNEL_CLASSES entries in this order:

@@ -86,6 +86,7 @@ def lib():
         L.orc_sp_candidates.restype = ip64
         L.orc_sp_build_table.argtypes = [C.c_void_p]
         L.orc_sp_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]
+        L.orc_sp_accumulate_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp, C.c_int]
         L.orc_sp_update.argtypes = [C.c_void_p, C.c_int, dp]
         L.orc_sp_update.restype = C.c_int
         L.orc_sp_finish.argtypes = [C.c_void_p]

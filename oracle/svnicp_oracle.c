@@ -434,7 +434,8 @@ static inline int correspond(const orc_solver *s, const double Rt[9], const doub
 #define CHUNK 2048 /* fixed chunking => results independent of the thread count */
 
 /* SVNICP.cpp:116-164 Newton_grad_right for particles [p_lo,p_hi): H [P][36], b [P][6] */
-static void newton_accumulate_range(orc_solver *s, int epoch, int p_lo, int p_hi, double *H, double *bv) {
+/* damping: add the 1e-6 diagonal of SVNICP.cpp:153 (0 when the caller sums several row-shard records first) */
+static void newton_accumulate_range(orc_solver *s, int epoch, int p_lo, int p_hi, double *H, double *bv, int damping) {
   const int P = s->P;
   const int64_t B = s->B;
   const int64_t nchunk = (B + CHUNK - 1) / CHUNK;
@@ -484,13 +485,13 @@ static void newton_accumulate_range(orc_solver *s, int epoch, int p_lo, int p_hi
       for (int i = 0; i < 36; ++i) Hp[i] += acc[i];
       for (int i = 0; i < 6; ++i) bp[i] += acc[36 + i];
     }
-    for (int i = 0; i < 6; ++i) Hp[7 * i] += 1e-6;                           /* :153 */
+    if (damping) for (int i = 0; i < 6; ++i) Hp[7 * i] += 1e-6;              /* :153 */
   }
   free(part);
 }
 
 static void newton_accumulate(orc_solver *s, int epoch, double *H, double *bv) {
-  newton_accumulate_range(s, epoch, 0, s->P, H, bv);
+  newton_accumulate_range(s, epoch, 0, s->P, H, bv, 1);
 }
 
 static int cmp_double(const void *a, const void *b) {
@@ -679,10 +680,22 @@ void orc_sp_candidate_rows(orc_solver *s, int64_t b_lo, int64_t b_hi) { candidat
 int64_t *orc_sp_candidates(orc_solver *s) { return s->cand_idx; }
 void orc_sp_build_table(orc_solver *s) { candidate_table(s); }
 /* rec: [P][42] = H (36) | b (6); only rows [p_lo,p_hi) are written */
+/* damping = 0: the record is one of several row-shard partials (this solver holds a slice of the source rows); the
+ * caller adds the records and then the 1e-6 diagonal (tests/oracle_backend.py) */
+void orc_sp_accumulate_rows(orc_solver *s, int epoch, int p_lo, int p_hi, double *rec, int damping) {
+  const int P = s->P;
+  double *H = (double *)malloc((size_t)P * 36 * 8), *bv = (double *)malloc((size_t)P * 6 * 8);
+  newton_accumulate_range(s, epoch, p_lo, p_hi, H, bv, damping);
+  for (int p = p_lo; p < p_hi; ++p) {
+    memcpy(rec + (size_t)p * 42, H + 36 * p, 36 * 8);
+    memcpy(rec + (size_t)p * 42 + 36, bv + 6 * p, 6 * 8);
+  }
+  free(H); free(bv);
+}
 void orc_sp_accumulate(orc_solver *s, int epoch, int p_lo, int p_hi, double *rec) {
   const int P = s->P;
   double *H = (double *)malloc((size_t)P * 36 * 8), *bv = (double *)malloc((size_t)P * 6 * 8);
-  newton_accumulate_range(s, epoch, p_lo, p_hi, H, bv);
+  newton_accumulate_range(s, epoch, p_lo, p_hi, H, bv, 1);
   for (int p = p_lo; p < p_hi; ++p) {
     memcpy(rec + (size_t)p * 42, H + 36 * p, 36 * 8);
     memcpy(rec + (size_t)p * 42 + 36, bv + 6 * p, 6 * 8);

@@ -110,6 +110,9 @@ void orc_sp_candidate_rows(orc_solver *s, int64_t b_lo, int64_t b_hi);
 int64_t *orc_sp_candidates(orc_solver *s);
 void orc_sp_build_table(orc_solver *s);
 void orc_sp_accumulate(orc_solver *s, int epoch, int p_lo, int p_hi, double *recPx42);
+/* the same for a solver that holds a SLICE of the source rows: damping = 0 leaves the 1e-6 diagonal to the caller, who adds
+ * the slices' records first (row-sharded multi-GPU layout, tests/oracle_backend.py) */
+void orc_sp_accumulate_rows(orc_solver *s, int epoch, int p_lo, int p_hi, double *recPx42, int damping);
 int orc_sp_update(orc_solver *s, int epoch, const double *recPx42);
 void orc_sp_finish(orc_solver *s);
 

@@ -110,10 +110,14 @@ def load_library():
     L.svnicp_get_knn_survivors.argtypes = [vp, ip]
     L.svnicp_get_knn_fallback_rows.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_int)]
     L.svnicp_get_ambiguous_steps.argtypes = [vp, C.POINTER(C.c_int)]
+    L.svnicp_get_ambiguous_pairs.argtypes = [vp, C.POINTER(C.c_int64)]
     L.svnicp_get_iterations_run.argtypes = [vp, C.POINTER(C.c_int)]
     L.svnicp_set_profile.argtypes = [vp, C.c_int]
     L.svnicp_get_kernel_ms.argtypes = [vp, dp, ip]
     L.svnicp_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    L.svnicp_set_row_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int64]
+    L.svnicp_rank_sums_devptr.argtypes = [vp]
+    L.svnicp_rank_sums_devptr.restype = vp
     L.svnicp_align_begin.argtypes = [vp]
     L.svnicp_stage_candidates.argtypes = [vp, C.c_int64, C.c_int64]
     L.svnicp_build_candidate_table.argtypes = [vp]

@@ -62,6 +62,11 @@ struct svnicp_ctx {
   DevBuf<float> txf, tyf, tzf, cmaxb;
   DevBuf<float4> tablef, tablea, tail;
   DevBuf<uint8_t> kbest;
+  // source-row sharding (svnicp_set_row_shard): this context holds rows of a larger scan; its per-iteration sums are one of
+  // row_world partial records that the host all-gathers into rank_sums [row_world][P][22]
+  int row_rank = 0, row_world = 1;
+  int64_t B_total = 0;
+  DevBuf<double> rank_sums;
   DevBuf<double> sl_d, fail_tau, anchor, qrec;
   DevBuf<int32_t> sl_i;
   int sliced_max = 0;  // set at align_begin (kFallbackSlicedMax or SVNICP_FALLBACK_SLICED_MAX)
@@ -90,6 +95,7 @@ struct svnicp_ctx {
   DevBuf<int32_t> full_idx;            // … and the nearest target of every (particle of the shard, source point): [P][B]
   unsigned long long* dbg_phase = nullptr;   // debug option: per-phase wave cycles of k_knn_tiles (per context, per device)
   unsigned long long* dbg_upd = nullptr;     // debug option: phase cycles of k_particle_update
+  bool finish_seen = true;   // the stop flag of the last registration has been folded into finish_iter
   int finish_iter = 0;   // finish_iter_: constructor value, changed only by an SVGD-mode early stop (SVGDICP.cpp:42,128)
   double gpu_ms[3] = {0, 0, 0};
   bool timing_valid = false;
@@ -226,7 +232,7 @@ void svnicp_destroy(svnicp_ctx* c) {
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
   for (auto* b : dbl) b->release();
-  c->eul.release(); c->opt.release(); c->uctl.release();
+  c->eul.release(); c->opt.release(); c->uctl.release(); c->rank_sums.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
   c->full_q.release(); c->full_d2.release(); c->full_idx.release(); c->arena.release(); c->chunk_tab.release();
   c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->tail.release(); c->kbest.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
@@ -312,6 +318,7 @@ int svnicp_set_particles(svnicp_ctx* c, const double* init, int P) {
   HIPCHK(c, c->uctl.ensure(update_uctl_doubles(P)));
   HIPCHK(c, hipMemcpyAsync(c->init_pose.p, init, (size_t)P * 48, hipMemcpyHostToDevice, c->stream));
   const bool first = !c->particles_set || P != c->P;
+  if (first && c->row_world > 1) { c->row_world = 1; c->row_rank = 0; c->B_total = 0; }   // the record array is sized by P: set the row shard again
   c->P = P;
   if (!c->shard_set || first) { c->p_lo = 0; c->p_hi = P; c->shard_set = false; }
   // ctor semantics: pose_particles_ is formed from the initial pose (SVNICP.cpp:36-37, SVGDICP.cpp:33-35);
@@ -382,6 +389,23 @@ int svnicp_set_shard(svnicp_ctx* c, int p_lo, int p_hi) {
   c->p_lo = p_lo; c->p_hi = p_hi; c->shard_set = true;
   return SVNICP_OK;
 }
+
+int svnicp_set_row_shard(svnicp_ctx* c, int row_rank, int row_world, int64_t total_source_points) {
+  CTX_CHECK(c);
+  if (!c->particles_set || row_world < 1 || row_rank < 0 || row_rank >= row_world || (row_world > 1 && total_source_points < 1))
+    return fail(c, SVNICP_ERR_INVALID, "svnicp_set_row_shard: need 0 <= row_rank < row_world and the whole scan's point count, after svnicp_set_particles");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  c->row_rank = row_rank; c->row_world = row_world;
+  c->B_total = row_world > 1 ? total_source_points : 0;
+  if (row_world > 1) {
+    HIPCHK(c, c->rank_sums.ensure((size_t)row_world * c->P * kNSums));
+    // a rank whose particle shard is empty in a 2-D split never writes its record: keep it defined
+    HIPCHK(c, hipMemsetAsync(c->rank_sums.p, 0, (size_t)row_world * c->P * kNSums * sizeof(double), c->stream));
+  }
+  return SVNICP_OK;
+}
+
+void* svnicp_rank_sums_devptr(svnicp_ctx* c) { return (c && c->row_world > 1) ? (void*)c->rank_sums.p : nullptr; }
 
 // (re)build the target SoA copies in the order the chosen stage-A kernel wants
 static int ensure_target_layout(svnicp_ctx* c) {
@@ -462,8 +486,8 @@ int svnicp_align_begin(svnicp_ctx* c) {
   HIPCHK(c, c->cand_d2.ensure((size_t)B * c->K));
   c->accum_mode = c->tune.accum;   // option "accum": f64 | valu | mfma | split
   HIPCHK(c, c->cmaxb.ensure((size_t)B));
-  HIPCHK(c, c->ambig.ensure(1));
-  HIPCHK(c, hipMemsetAsync(c->ambig.p, 0, sizeof(int), c->stream));
+  HIPCHK(c, c->ambig.ensure(2));   // [0] wave steps with an undecided lane, [1] undecided (point, particle) pairs
+  HIPCHK(c, hipMemsetAsync(c->ambig.p, 0, 2 * sizeof(int), c->stream));
   HIPCHK(c, c->history.ensure((size_t)(I > 0 ? I : 1) * 6 * P));
   c->hist_I = I; c->hist_P = P;
   const int nshard = c->p_hi - c->p_lo;
@@ -500,6 +524,15 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->trh.p, 0, ((size_t)I + 1) * 8, c->stream));
   }
   c->pused = 0;
+  if (!c->finish_seen && c->prm.mode == SVNICP_MODE_SVGD && c->prm.check_early_stop) {
+    // finish_iter_ is sticky across registrations (SVGDICP.cpp:42,128): fold the previous registration's stop flag in before
+    // the control words are reset, in case nobody asked for svnicp_get_runtime in between (SVGD mode with early stop only)
+    int v[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(v, c->ctl.p, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (v[0]) c->finish_iter = v[1];
+    c->finish_seen = true;
+  }
   const int ctl_init[4] = {0, I, 0, 0};  // stop flag, finish_iter (SVGDICP.cpp:42)
   HIPCHK(c, hipMemcpyAsync(c->ctl.p, ctl_init, sizeof ctl_init, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->history.p, 0, (size_t)(I > 0 ? I : 1) * 6 * P * sizeof(float), c->stream));  // SVGDICP.cpp:172-174
@@ -510,6 +543,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->opt.p, 0, (size_t)P * 18 * sizeof(double), c->stream));
   c->particles_dirty = false;
   c->began = true;
+  c->finish_seen = false;
   c->have_result = false;
   c->timing_valid = false;
   return SVNICP_OK;
@@ -677,8 +711,9 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   HIPCHK(c, launch_accumulate(c->plan, a, c->stream));
   HIPCHK(c, prof_end(c));
   HIPCHK(c, prof_begin(c, KC_REDUCE));
-  HIPCHK(c, launch_reduce_partials(c->partial.p, c->plan.grid_x, c->plan.Ppad, c->p_lo, nshard, c->sums.p, c->ctl.p,
-                                   c->stream));
+  // one rank: the particle's record; source-row sharding: this rank's slot of the [row_world][P][22] array
+  double* rec = c->row_world > 1 ? c->rank_sums.p + (size_t)c->row_rank * c->P * kNSums : c->sums.p;
+  HIPCHK(c, launch_reduce_partials(c->partial.p, c->plan.grid_x, c->plan.Ppad, c->p_lo, nshard, rec, c->ctl.p, c->stream));
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;
 }
@@ -689,7 +724,7 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
   if (it < 0 || it >= c->prm.iterations) return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_update: bad iteration");
   if (bind(c)) return SVNICP_ERR_HIP;
   UpdateArgs u{};
-  u.sums = c->sums.p; u.R = c->R.p; u.t = c->t.p; u.Rtot = c->Rtot.p; u.pose = c->pose0;
+  u.sums = c->row_world > 1 ? c->rank_sums.p : c->sums.p; u.n_ranks = c->row_world; u.R = c->R.p; u.t = c->t.p; u.Rtot = c->Rtot.p; u.pose = c->pose0;
   u.P = c->P; u.iteration = it; u.iterations = c->prm.iterations;
   u.lr = c->prm.lr; u.conv_thr = c->prm.convergence_threshold;
   u.check_early_stop = c->prm.check_early_stop; u.full_grad = c->prm.svn_full_grad;
@@ -698,7 +733,8 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
     u.trH = c->trH.p + (size_t)it * c->P * 36; u.trb = c->trb.p + (size_t)it * c->P * 6;
     u.trN = c->trN.p + (size_t)it * c->P * 6; u.trphi = c->trphi.p + (size_t)it * c->P * 6; u.trh = c->trh.p + it;
   }
-  u.eul = c->eul.p; u.opt = c->opt.p; u.optimizer = c->prm.optimizer; u.n_src = (double)c->B;
+  u.eul = c->eul.p; u.opt = c->opt.p; u.optimizer = c->prm.optimizer;
+  u.n_src = (double)(c->row_world > 1 ? c->B_total : c->B);   // gradient_scaling_factor_ = the whole scan's size (SVGDICP.cpp:58)
   HIPCHK(c, prof_begin(c, KC_UPDATE));
   u.uctl = c->uctl.p;
   unsigned long long*& dbg_upd = c->dbg_upd;     // debug option: phase cycles of k_particle_update, printed at finish
@@ -770,14 +806,11 @@ int svnicp_align(svnicp_ctx* c) {
   CTX_CHECK(c);
   if (c->shard_set && (c->p_lo != 0 || c->p_hi != c->P))
     return fail(c, SVNICP_ERR_INVALID, "svnicp_align: a particle shard is set; drive the split-phase calls instead");
+  if (c->row_world > 1)
+    return fail(c, SVNICP_ERR_INVALID, "svnicp_align: a source-row shard is set (this context holds a partial record); drive the split-phase calls instead");
   int rc = svnicp_align_async(c);
   if (rc) return rc;  // negative status, or SVNICP_NO_OPTIMIZER
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->prm.mode == SVNICP_MODE_SVGD && c->prm.check_early_stop) {  // finish_iter_ = epoch + 1 (SVGDICP.cpp:128)
-    int v[2] = {0, 0};
-    HIPCHK(c, hipMemcpy(v, c->ctl.p, sizeof v, hipMemcpyDeviceToHost));
-    if (v[0]) c->finish_iter = v[1];
-  }
   return SVNICP_ALIGN_SUCCESS;
 }
 
@@ -824,8 +857,16 @@ int svnicp_get_gpu_ms(svnicp_ctx* c, double out3[3]) {
 int svnicp_get_runtime(svnicp_ctx* c, double out3[3]) {
   NEED_RESULT(c);
   double ms[3];
-  int rc = svnicp_get_gpu_ms(c, ms);
+  int rc = svnicp_get_gpu_ms(c, ms);   // synchronises the stream
   if (rc) return rc;
+  if (c->prm.mode == SVNICP_MODE_SVGD && c->prm.check_early_stop && !c->finish_seen) {
+    // finish_iter_ = epoch + 1 on an SVGD-mode early stop (SVGDICP.cpp:128).  Read here rather than in svnicp_align so that
+    // svnicp_align_async + svnicp_synchronize and the split-phase sequence (svnicp_iter_update … svnicp_finish) report it too
+    int v[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(v, c->ctl.p, sizeof v, hipMemcpyDeviceToHost));
+    if (v[0]) c->finish_iter = v[1];
+    c->finish_seen = true;
+  }
   // finish_iter_: SVNICP::stein_align never touches it (SVNICP.cpp:95-101 only breaks), SVGDICP::stein_align sets it on
   // an early stop and nothing resets it (SVGDICP.cpp:42,128)
   out3[0] = ms[0] * 1e-3; out3[1] = ms[1] * 1e-3; out3[2] = (double)c->finish_iter;
@@ -875,6 +916,16 @@ int svnicp_get_ambiguous_steps(svnicp_ctx* c, int* out) {
   if (!c->have_result) return fail(c, SVNICP_ERR_INVALID, "no registration result yet");
   if (c->accum_mode == 0) { *out = -1; return SVNICP_OK; }
   return fetch(c, out, c->ambig.p, sizeof(int));
+}
+
+int svnicp_get_ambiguous_pairs(svnicp_ctx* c, int64_t* out) {
+  CTX_CHECK(c);
+  if (!c->have_result || !out) return fail(c, SVNICP_ERR_INVALID, "no registration result yet");
+  if (c->accum_mode != 3 || c->plan.f32 != 3 || c->plan.search_f32) { *out = -1; return SVNICP_OK; }   // counted by the bf16 search kernel only
+  int v[2] = {0, 0};
+  const int rc = fetch(c, v, c->ambig.p, sizeof v);
+  *out = v[1];
+  return rc;
 }
 
 int svnicp_set_profile(svnicp_ctx* c, int on) {

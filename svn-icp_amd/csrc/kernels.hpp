@@ -173,7 +173,8 @@ hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int
 
 // ---------------- particle update (particle_update.hip) ----------------
 struct UpdateArgs {
-  const double* sums;  // [P][kNSums] (all particles)
+  const double* sums;  // [P][kNSums] (all particles); source-row sharding: [n_ranks][P][kNSums], summed in rank order on load
+  int n_ranks;         // 1, or the number of row-shard records behind `sums`
   double* R;           // [P][9]
   double* t;           // [P][3]
   double* Rtot;        // [P][12]

@@ -61,6 +61,20 @@ __device__ void finalize_Hb(const double* s, const double* Rc, double* H, double
   b[5] = G[3] - G[1];
 }
 
+// The 22 raw sums of particle p.  One rank (or particle sharding): the context's own record.  Source-row sharding
+// (svnicp_set_row_shard): a.sums is the all-gathered [n_ranks][P][22] array of the ranks' partial records — rank r summed
+// its own source rows — and every rank adds the same records in the same (rank) order, so the replicas stay bit-identical.
+__device__ __forceinline__ void load_sums(const UpdateArgs& a, int p, double* s) {
+  const double* rec = a.sums + (size_t)p * kNSums;
+#pragma unroll
+  for (int i = 0; i < kNSums; ++i) s[i] = rec[i];
+  for (int r = 1; r < a.n_ranks; ++r) {
+    rec += (size_t)a.P * kNSums;
+#pragma unroll
+    for (int i = 0; i < kNSums; ++i) s[i] += rec[i];
+  }
+}
+
 // shared state of the exact-median selection
 struct SelShared {
   unsigned int hist[256];
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
     double Rc[9], H[36], b[6], LU[36], x6[6];
     int piv[6];
     mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
-    finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
+    { double sm[kNSums]; load_sums(a, p, sm); finalize_Hb(sm, Rc, H, b); }
 #pragma unroll
     for (int i = 0; i < 36; ++i) { LU[i] = H[i]; if (lH) lH[p * 36 + i] = H[i]; }
     if (!lH || a.trH) {
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(128) void k_upd_prepare(UpdateArgs a) {
     double Rc[9], H[36], b[6], LU[36], x6[6];
     int piv[6];
     mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
-    finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
+    { double sm[kNSums]; load_sums(a, p, sm); finalize_Hb(sm, Rc, H, b); }
 #pragma unroll
     for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; sh_H[threadIdx.x * 37 + i] = H[i]; }
     const bool ok = lu6(LU, piv);
@@ -732,7 +746,7 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
     for (int p = tid; p < P; p += UT) {
       double Rc[9], H[36], b[6];
       mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
-      finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
+      { double sm[kNSums]; load_sums(a, p, sm); finalize_Hb(sm, Rc, H, b); }
 #pragma unroll
       for (int i = 0; i < 36; ++i) lH[p * 36 + i] = H[i];
     }
@@ -777,7 +791,7 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
       double Rc[9], H[36], b[6], LU[36], x6[6];
       int piv[6];
       mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
-      finalize_Hb(a.sums + (size_t)p * kNSums, Rc, H, b);
+      { double sm[kNSums]; load_sums(a, p, sm); finalize_Hb(sm, Rc, H, b); }
 #pragma unroll
       for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; }
       const bool ok = lu6(LU, piv);
@@ -1145,7 +1159,8 @@ __device__ void euler_partials(const double* R0, double roll, double pitch, doub
 // sgd_grad of one particle from the raw sums (SVGDICP.cpp:398-455): Euler-angle partials, (count + 1) normalisation,
 // scaled by the source size
 __device__ void svgd_gradient(const UpdateArgs& a, int p, double* g6) {
-  const double* s = a.sums + (size_t)p * kNSums;
+  double s[kNSums];
+  load_sums(a, p, s);
   const double* eu = a.eul + 6 * p;
   double dR[3][9];
   euler_partials(a.pose.R0, eu[3], eu[4], eu[5], dR);

@@ -297,7 +297,9 @@ __global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict_
       }
       cx = (float)(x - a0); cy = (float)(y - a1); cz = (float)(z - a2);
       cc = (float)(((double)cx * cx + (double)cy * cy) + (double)cz * cz);
-      cm = __builtin_fmaxf(cm, __builtin_fmaxf(__builtin_fabsf(cx), __builtin_fmaxf(__builtin_fabsf(cy), __builtin_fabsf(cz))));
+      // C_b = max |c'|_2 over the point's candidates, rounded up (>= max |c'|_inf, which is all the f32 kernels' bounds need;
+      // the bf16 search kernel's bound is written in the 2-norm, stein_split.hip)
+      cm = __builtin_fmaxf(cm, (float)sqrt(((double)cx * cx + (double)cy * cy) + (double)cz * cz) * 1.0000002f);
       if (!(cc < kSentinelCC)) cm = __builtin_nanf("");  // huge or NaN rows: every step of this point takes the exact path
     }
     rb[4 * k] = cx; rb[4 * k + 1] = cy; rb[4 * k + 2] = cz; rb[4 * k + 3] = cc;

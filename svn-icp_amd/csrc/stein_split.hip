@@ -221,13 +221,39 @@ __global__ __launch_bounds__(NT, 4) void k_stein_search_mfma(AccumArgs a) {
 // The dropped products (a2·b3, a3·b2, a3·b3) are below 2·2^-24·|c_d·m_d| per component.
 // The per-particle term |x'|² is the same for every candidate and is left out: the scores S = cc + c'·m are compared as
 // (signed) floats, the accumulator input is the constant 0.
-// Error bound (u = 2^-24; C, X as in stein_mfma.hip): inputs 9.1uC² + 12.1uXC as before; dropped products
-// <= 2u·3·C·2X = 12uCX <= 3u(C+X)²; the matrix pipe's accumulation of the 21 exact terms: measured over 1.2e8
-// scores incl. cancelling ones (tests/microbench/mfma_bf16x3_err.hip) at most 3.8u·Σ|terms| = 9.8u(C+X)², budgeted
-// here as 16u·Σ|terms| <= 48u(C+X)²  =>  EPS := 64·u·(C+X)².  Packing the slot into the low 7 mantissa bits moves a
-// score by < 2^-16·|S|.  If  b2 − b1 > 2·EPS + 2^-15·(|b1| + |b2|)  every other candidate is strictly farther in exact
-// arithmetic and the packed argmin is the f64 argmin; ties, padded duplicates, NaN/Inf never pass and go to the exact
-// f64 pass.  Tracking: slot packing is v_bitop3_b32 (full-rate VALU class; v_and_or_b32, v_min_*, v_med3_* issue at 0.6x).
+// Error bound (u = 2^-24) — every term is a worst case, nothing in it is measured.  Notation: a = the point's first
+// candidate (origin of the local frame), y_k = q_k − a and x = T_p(s) − a in exact arithmetic, s_k = |y_k|² − 2 y_k·x =
+// |T − q_k|² − |x|² the exact score; c_k = fl32(y_k), cc_k = fl32(|c_k|²), m = −2·fl32(x) the float32 inputs;
+// C2 = max_k |c_k|₂ (cmax[], rounded up), X2 = |fl32(x)|₂.
+//   (i)   inputs: each coordinate is rounded twice (f64 subtraction, f32 conversion), relative 1.0001u; cc once more:
+//         |cc_k − |y_k|²| <= 3.01u·C2², |c_k·m − (−2 y_k·x)| <= 4.01u·C2·X2
+//   (ii)  dropped products a2·b3, a3·b2, a3·b3 (|a2| <= 2^-8·1.004|a|, |a3| <= 2^-16|a|): <= 2.02u·Σ_d|c_d m_d| <= 4.04u·C2·X2
+//   (iii) the matrix pipe's sum of the 21 non-zero products (each exact in float32: 8-bit x 8-bit significands; the 11
+//         zero products and the zero accumulator input add nothing).  Σ|products| <= 1.008·cc_k + 1.016·Σ_d|c_d m_d| <=
+//         1.009·C2² + 2.032·C2·X2.  The hardware's summation is not documented, so the budget is the larger of the two
+//         worst cases that exist for a float32 adder tree: (a) ANY order of 20 two-operand additions, each faithfully
+//         rounded or truncated (relative error <= 2u per addition): (1+2u)^20 − 1 <= 40.01u; (b) a fused adder that
+//         aligns all products to the largest exponent, truncates each to >= 24 bits and rounds once: 20·2u + 2u = 42u.
+//         Budget 48u·Σ|products| <= 48.5u·C2² + 97.6u·C2·X2.  (What gfx950 does, from the probes of
+//         tests/microbench/mfma_bf16x3_err.hip: model (b) with 25 bits kept and round-to-nearest-even at the end, worst
+//         case 21u; largest error seen on adversarial operands 5.7u.)
+//   (iv)  the reference's own float64 evaluation of d²_k: <= 5·2^-53·|T − q_k|² <= 2^-50·(C2 + X2)²
+//   sum <= 51.5u·C2² + 105.7u·C2·X2 + 2^-50(C2+X2)²  <=  EPS := 54·u·Cq·(Cq + 2·X2),  Cq = C2 + u·X2
+//   (the u·X2 in Cq keeps (iv) covered when the candidates are closer together than 2^-24 of their distance to the point).
+// Round 2 used 64u(C∞+X∞)² with (iii) budgeted from a measurement; written in the ∞-norms this bound would be
+// 160u(C∞+X∞)² — the 2-norms are what keeps the proven bound as tight as the measured one was.
+// tests/test_gpu_parity.py::test_mfma_bf16x3_error_budget runs the microbenchmark (the kernel's operand construction on
+// random, cancelling and extreme-ratio inputs; arbitrary bf16 operands in the 21 live slots: half-ulp ties, terms just
+// below one ulp, graded magnitudes with alternating signs, cancelling pairs, 40 binades of exponents, every rotation over
+// the slots) and fails when any result is off by more than HALF of (iii)'s budget — a matrix pipe that behaved worse than
+// every model above would be noticed, not trusted.
+// Packing the slot into the low 7 mantissa bits moves a score by < 127 ulp < 2^-16·|S|.  With b1, b2 the smallest and
+// second smallest PACKED scores, every other candidate's unpacked score is >= b2 − 2^-16|b2| and the winner's is
+// <= b1 + 2^-16|b1|; so if
+//   b2 − b1 > 2·EPS + 2^-16·(1 + 2^-8)·(|b1| + |b2|)
+// every other candidate is strictly farther in exact arithmetic and the packed argmin is the f64 argmin; ties, padded
+// duplicates, NaN/Inf never pass and go to the exact f64 pass.  Tracking: slot packing is v_bitop3_b32 (full-rate VALU
+// class; v_and_or_b32, v_min_*, v_med3_* issue at 0.6x).
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
@@ -314,7 +340,10 @@ __device__ __forceinline__ int exact_nearest_of_k(const AccumArgs& a, const doub
   return (d0 != d0 || bk == 0x7fffffff) ? 0 : bk;
 }
 
-constexpr float kEpsBf16 = 64.0f * 5.9604644775390625e-08f;
+#ifndef SVNICP_SEARCH_EPS_U
+#define SVNICP_SEARCH_EPS_U 54   // derivation: header of this section (another value is only ever built to MEASURE what the bound costs)
+#endif
+constexpr float kEpsBf16 = (float)SVNICP_SEARCH_EPS_U * 5.9604644775390625e-08f;
 
 // Work split: all four waves of a workgroup walk source points (one point per wave step when PW = 64); a wave handles
 // ALL WP groups of PW particles of its points one after the other, so a point's table rows are fetched and split into
@@ -409,8 +438,10 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
         const double T1 = (s0 * pose[3][lane] + s1 * pose[4][lane] + s2 * pose[5][lane]) + pose[10][lane];
         const double T2 = (s0 * pose[6][lane] + s1 * pose[7][lane] + s2 * pose[8][lane]) + pose[11][lane];
         const float xf0 = (float)(T0 - a0), xf1 = (float)(T1 - a1), xf2 = (float)(T2 - a2);
-        const float X = __builtin_fmaxf(__builtin_fabsf(xf0), __builtin_fmaxf(__builtin_fabsf(xf1), __builtin_fabsf(xf2)));
-        E = kEpsBf16 * (C + X) * (C + X);
+        // EPS = 54u·Cq·(Cq + 2·X2); v_sqrt_f32 is good to 1 ulp, the factor covers it and the roundings of this line
+        const float X2 = __builtin_amdgcn_sqrtf(__builtin_fmaf(xf0, xf0, __builtin_fmaf(xf1, xf1, xf2 * xf2))) * 1.000002f;
+        const float Cq = __builtin_fmaf(5.9604644775390625e-08f, X2, C);   // NaN (a sentinel row, a non-finite point) stays NaN
+        E = kEpsBf16 * Cq * __builtin_fmaf(2.0f, X2, Cq);
         if (g > 0) __builtin_amdgcn_wave_barrier();      // the previous group's readers are done with the scratch
         s_scr4[wave][lane] = make_float4(-2.0f * xf0, -2.0f * xf1, -2.0f * xf2, 1.0f);
         __builtin_amdgcn_wave_barrier();
@@ -520,7 +551,7 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
       const bool valid = inb && (a.p_lo + pbase + pin) < a.p_hi;
       const unsigned int wbits = __float_as_uint(b1own);
       int kb = (int)(((wbits & 0x1cu) << 2) | ((wbits >> 3) & 0xcu) | (wbits & 3u));  // 16·rb + 4·mk + v
-      const float thr = 2.0f * E + 3.0517578125e-05f * (__builtin_fabsf(b1own) + __builtin_fabsf(b2own)) + 1.0e-30f;
+      const float thr = 2.0f * E + 1.5318394e-05f * (__builtin_fabsf(b1own) + __builtin_fabsf(b2own)) + 1.0e-30f;   // 2^-16·(1 + 2^-8)
       const bool ambiguous = valid && (!(b2own - b1own > thr) || kb >= K);
       kb = kb < K ? kb : 0;
       unsigned long long am = __ballot(ambiguous);
@@ -563,7 +594,7 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
       const int ke = exact_nearest_of_k<kExactLanes>(a, s_pose[pin / PW], be, pin % PW, K, sub);
       if (sub == 0) a.kbest[(size_t)be * a.Ppad + (pbase + pin)] = (uint8_t)ke;
     }
-    if (tid == 0 && a.ambig_count && s_qsteps) atomicAdd(a.ambig_count, (int)s_qsteps);
+    if (tid == 0 && a.ambig_count && s_qsteps) { atomicAdd(a.ambig_count, (int)s_qsteps); atomicAdd(a.ambig_count + 1, (int)s_qn); }
   }
 }
 
@@ -624,31 +655,54 @@ __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulat
   // The reference zeroes a rejected row by multiplying with the mask (SVGDICP.cpp:331-333): e = 0, |e| = 0, so w = 1 and
   // J = [R | 0] — the same products are formed here (mf = 0 or 1), which also makes the pair branch-free.
   // `on`: 1.0 for a pair that exists, 0.0 for a point past the block (padding particle lanes are never read back).
+  //
+  // Instruction diet of round 3 (this kernel issues ~one f64 instruction per 3.3 cycles per SIMD; 78 -> 63 per pair):
+  //  * the transform and d² are fused multiply-adds (9 + 3 instead of 18 + 5): Ts and d² differ from the search kernel's
+  //    unfused values by one rounding (<= 2^-52 relative); they only feed the mask, the weight and e here;
+  //  * sqrt and the division are v_rsq_f64 / v_rcp_f64 seeds refined by hand.  The seeds are only good to about 2^-13
+  //    relative on this chip (measured, tests/microbench/f64_seed_accuracy.hip; the first version assumed 2^-23 and was
+  //    1.2e-12 off in H), so: root = one coupled Goldschmidt step on (s, h = r/2) — 1.5·2^-26 — then one residual step
+  //    with the refined h — about 2^-51; quotient = two Newton steps, 2^-26 then 2^-52.  The compiler's IEEE sequences
+  //    spend ten more instructions on scaling for denormals, on the last half ulp and on special cases that cannot
+  //    occur here.  The weight is formed as 1 / (1 + (3/d)·|e|) with 3/d rounded once per launch: w agrees with the
+  //    reference's (d / (d + 3|e|))² to a few 2^-52 relative (tests hold the sums to 1e-12 against the f64 kernel);
+  //  * mask·s is not formed: w·(mask·s) = (mask·w)·s exactly, because the mask is 0 or 1.
+  const double c3d = 3.0 / a.max_dist;
   auto accumulate = [&](double on, double s0, double s1, double s2, double q0, double q1, double q2) {
-    const double T0 = (s0 * Rt[0] + s1 * Rt[1] + s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64
-    const double T1 = (s0 * Rt[3] + s1 * Rt[4] + s2 * Rt[5]) + tt[1];
-    const double T2 = (s0 * Rt[6] + s1 * Rt[7] + s2 * Rt[8]) + tt[2];
+    const double T0 = fma(s2, Rt[2], fma(s1, Rt[1], fma(s0, Rt[0], tt[0])));   // SVNICP.cpp:62-64
+    const double T1 = fma(s2, Rt[5], fma(s1, Rt[4], fma(s0, Rt[3], tt[1])));
+    const double T2 = fma(s2, Rt[8], fma(s1, Rt[7], fma(s0, Rt[6], tt[2])));
     const double dx = T0 - q0, dy = T1 - q1, dz = T2 - q2;
-    const double best = (dx * dx + dy * dy) + dz * dz;   // exact d² of the winner (knn_cpu.cpp:43-50 order)
-    const double mf = best < a.max_dist ? on : 0.0;       // point_filter, SVGDICP.cpp:331-333
-    const double nn = sqrt(mf * best);                    // SVNICP.cpp:120 on the masked rows
-    const double wq = a.max_dist / (a.max_dist + 3 * nn);
-    const double w = on * (wq * wq);                      // SVNICP.cpp:122 (exactly 1 for a rejected row)
+    const double best = fma(dx, dx, fma(dy, dy, dz * dz));   // d² of the winner
+    const double mf = best < a.max_dist ? on : 0.0;       // point_filter, SVGDICP.cpp:331-333 (squared distance against max_dist)
+    const double x = mf * best;                           // 0 for a rejected row; NaN stays NaN (a non-finite point)
+    // |e| = sqrt(x), SVNICP.cpp:120 on the masked rows: rsq seed (x + 2^-1000 keeps x = 0 finite: 0·2^500 = 0), s = x·r,
+    // one coupled Newton step on (s, h = r/2), one residual step on s
+    const double r0 = __builtin_amdgcn_rsq(x + 0x1p-1000);
+    const double sa = x * r0, h0 = 0.5 * r0;
+    const double ea = fma(-h0, sa, 0.5);
+    const double sb = fma(sa, ea, sa), hb = fma(h0, ea, h0);
+    const double nn = fma(fma(-sb, sb, x), hb, sb);
+    // wq = d / (d + 3|e|) = 1 / (1 + (3/d)|e|), SVNICP.cpp:121-122: rcp seed + two Newton steps; exactly 1 for a rejected row
+    const double den = fma(c3d, nn, 1.0);
+    const double y0 = __builtin_amdgcn_rcp(den);
+    const double y1 = fma(y0, fma(-den, y0, 1.0), y0);
+    const double wq = fma(y1, fma(-den, y1, 1.0), y1);
+    const double w = on * (wq * wq);                      // SVNICP.cpp:122
     const double we = mf * w;
     const double e0 = we * dx, e1 = we * dy, e2 = we * dz;  // SVNICP.cpp:119,123
-    const double n0 = mf * s0, n1 = mf * s1, n2 = mf * s2;
-    const double w0 = w * n0, w1 = w * n1, w2 = w * n2;
+    const double w0 = we * s0, w1 = we * s1, w2 = we * s2;
     acc[0] += w;
     acc[1] += w0; acc[2] += w1; acc[3] += w2;
     // SVGD mode needs count_nonzero(mask·Ts summed over xyz) (SVGDICP.cpp:404) instead of Σw·s_x²
     if (PLAIN ? SVGD : (a.svgd != 0)) acc[4] += (((T0 + T1) + T2) != 0.0) ? mf : 0.0;
-    else acc[4] = fma(w0, n0, acc[4]);
-    acc[5] = fma(w0, n1, acc[5]); acc[6] = fma(w0, n2, acc[6]);
-    acc[7] = fma(w1, n1, acc[7]); acc[8] = fma(w1, n2, acc[8]); acc[9] = fma(w2, n2, acc[9]);
+    else acc[4] = fma(w0, s0, acc[4]);
+    acc[5] = fma(w0, s1, acc[5]); acc[6] = fma(w0, s2, acc[6]);
+    acc[7] = fma(w1, s1, acc[7]); acc[8] = fma(w1, s2, acc[8]); acc[9] = fma(w2, s2, acc[9]);
     acc[10] += e0; acc[11] += e1; acc[12] += e2;
-    acc[13] = fma(e0, n0, acc[13]); acc[14] = fma(e0, n1, acc[14]); acc[15] = fma(e0, n2, acc[15]);
-    acc[16] = fma(e1, n0, acc[16]); acc[17] = fma(e1, n1, acc[17]); acc[18] = fma(e1, n2, acc[18]);
-    acc[19] = fma(e2, n0, acc[19]); acc[20] = fma(e2, n1, acc[20]); acc[21] = fma(e2, n2, acc[21]);
+    acc[13] = fma(e0, s0, acc[13]); acc[14] = fma(e0, s1, acc[14]); acc[15] = fma(e0, s2, acc[15]);
+    acc[16] = fma(e1, s0, acc[16]); acc[17] = fma(e1, s1, acc[17]); acc[18] = fma(e1, s2, acc[18]);
+    acc[19] = fma(e2, s0, acc[19]); acc[20] = fma(e2, s1, acc[20]); acc[21] = fma(e2, s2, acc[21]);
   };
 
   const int64_t n0 = blk_lo + wb * BW;

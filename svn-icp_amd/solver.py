@@ -306,6 +306,12 @@ class _SolverBase:
         self._check(self._L.svnicp_get_ambiguous_steps(self._h, C.byref(v)), "svnicp_get_ambiguous_steps")
         return int(v.value)
 
+    def get_ambiguous_pairs(self) -> int:
+        """(point, particle) pairs the bf16 matrix-pipe search handed to its exact float64 pass (-1: another search kernel)."""
+        v = C.c_int64(0)
+        self._check(self._L.svnicp_get_ambiguous_pairs(self._h, C.byref(v)), "svnicp_get_ambiguous_pairs")
+        return int(v.value)
+
     def get_candidate_dist2(self) -> np.ndarray:
         return self._getd("candidate_dist2", self._B * self._K).reshape(self._B, self._K)
 

@@ -31,11 +31,16 @@ class OracleBackend:
     def set_shard(self, lo, hi):
         self.p_lo, self.p_hi = lo, hi
 
+    def set_row_shard(self, row_rank, row_world, total_rows):
+        """Source rows sharded: this solver holds a slice of the scan; its H, b are partial records."""
+        self.row_rank, self.row_world = row_rank, row_world
+
     def align_begin(self):
         self.L.orc_sp_begin(self.solver.h)
         self._stop = False
         self._cand32 = np.zeros((self.B, self.K), np.int32)
         self._rec = np.zeros((self.P, self.record_width), np.float64)
+        self._rank_rec = np.zeros((getattr(self, "row_world", 1) * self.P, self.record_width), np.float64)
 
     def stage_candidates(self, lo, hi):
         self.L.orc_sp_candidate_rows(self.solver.h, lo, hi)
@@ -53,15 +58,30 @@ class OracleBackend:
     def iter_accumulate(self, it):
         if self._stop:
             return
+        if getattr(self, "row_world", 1) > 1:
+            own = self._rank_rec[self.row_rank * self.P:(self.row_rank + 1) * self.P]
+            self.L.orc_sp_accumulate_rows(self.solver.h, it, self.p_lo, self.p_hi, own.ctypes.data_as(C.POINTER(C.c_double)), 0)
+            return
         self.L.orc_sp_accumulate(self.solver.h, it, self.p_lo, self.p_hi,
                                  self._rec.ctypes.data_as(C.POINTER(C.c_double)))
 
     def records_tensor(self):
         return torch.from_numpy(self._rec)
 
+    def rank_records_tensor(self):
+        return torch.from_numpy(self._rank_rec)
+
     def iter_update(self, it):
         if self._stop:
             return
+        if getattr(self, "row_world", 1) > 1:   # the records in rank order, then the damping (SVNICP.cpp:153), as the HIP update does
+            r = self._rank_rec.reshape(self.row_world, self.P, self.record_width)
+            acc = r[0].copy()
+            for g in range(1, self.row_world):
+                acc += r[g]
+            for i in range(6):
+                acc[:, 7 * i] += 1e-6
+            self._rec[:] = acc
         self._stop = bool(self.L.orc_sp_update(self.solver.h, it, self._rec.ctypes.data_as(C.POINTER(C.c_double))))
 
     def finish(self):

@@ -2,6 +2,7 @@
 vectors.  Bars (BASELINE.json north_star): correspondence indices bit-exact under brute-force NN,
 final SE(3) pose within 1e-4 m / 1e-4 rad.  The small cases are held to ~1e-9."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -39,6 +40,32 @@ def _compare(s, o, tro, P, strict_pose=TIGHT):
     assert np.allclose(s.get_particles(), o.get_particles(), atol=strict_pose)
     assert np.array_equal(s.get_particle_weight(), o.get_particle_weight())
     assert np.allclose(s.get_particle_history(), o.get_particle_history(), atol=1e-6)
+
+
+# ------------------------------------------------------------------ the matrix pipe behind the search certificate
+def test_mfma_bf16x3_error_budget():
+    """The exactness certificate of k_stein_search_bf16 budgets the accumulation error of v_mfma_f32_16x16x32_bf16 at
+    48·u·Σ|products| — the worst case of any faithfully rounding or truncating float32 adder tree over the 21 live
+    products (svn-icp_amd/csrc/stein_split.hip).  That bound is a statement about arithmetic, not about
+    this chip; this gate runs the kernel's own operand construction and adversarial operand sets (half-ulp ties, terms
+    just below one ulp, graded magnitudes with alternating signs, cancelling pairs, 40 binades of exponents, every rotation
+    over the live K slots) on the device and fails when any result is off by more than HALF of the budget."""
+    import os
+    import re
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "microbench", "mfma_bf16x3_err")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(here, "microbench")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout)
+    m = re.search(r"RESULT split_max=([0-9.eE+-]+) adversarial_max=([0-9.eE+-]+) split_inexact=(\d+)", r.stdout)
+    assert m, r.stdout
+    split_max, adv_max, inexact = float(m.group(1)), float(m.group(2)), int(m.group(3))
+    assert inexact == 0, "a float32 operand was not split exactly into three bf16 pieces"
+    assert split_max <= 24.0, f"accumulation error {split_max} u·Σ|products| on the kernel's operands exceeds half of the 48u budget"
+    assert adv_max <= 24.0, f"accumulation error {adv_max} u·Σ|products| on adversarial operands exceeds half of the 48u budget"
 
 
 # ------------------------------------------------------------------ golden fixtures (SVN mode)
@@ -100,6 +127,37 @@ def test_hip_svgd_reproduces_golden_and_oracle(hip, orc, name):
     o = oracle_from_golden(orc, g); o.stein_align()
     assert int(s.get_runtime()[2]) == o.finish_iter() and s.get_iterations_run() == o.iterations_run()
     assert np.allclose(s.get_particles(), o.get_particles(), rtol=0, atol=TIGHT)
+
+
+def test_finish_iter_on_async_and_split_phase_paths(hip, orc):
+    """finish_iter_ (svnicp_get_runtime()[2], Runtime.msg) after an SVGD-mode early stop must not depend on which entry
+    point ran the registration: the blocking svnicp_align, svnicp_align_async + svnicp_synchronize, and the split-phase
+    sequence of the sharded driver all report epoch + 1 (SVGDICP.cpp:128)."""
+    from svnicp_amd.sharded import ShardedSVGDICP
+    P, B, M, I = 12, 600, 3000, 8
+    src, tgt = hip.scans.random_clouds(B, M, seed=41)
+    init = hip.scans.make_particles(P, seed=41) * 0.3
+    cfg = dict(iterations=I, lr=0.01, max_dist=1.0, check_early_stop=True, convergence_threshold=0.05, knn_count=16, optimizer="Adam")
+    o = orc.Solver(init, mode=orc.MODE_SVGD, svn_full_grad=False, **cfg); o.add_cloud(src, tgt, init); o.stein_align()
+    assert o.iterations_run() < I, "the early stop must fire for this test to mean anything"
+    fi = o.finish_iter()
+    prm = hip.SteinICPParam(iterations=I, lr=0.01, max_dist=1.0, check_early_stop=True, convergence_threshold=0.05, KNN_count=16,
+                            optimizer="Adam")
+    a = hip.SVGDICP(prm, init); a.add_cloud(src, tgt, init); a.stein_align()
+    assert int(a.get_runtime()[2]) == fi
+    b = hip.SVGDICP(prm, init); b.add_cloud(src, tgt, init); b.stein_align_async(); b.synchronize()
+    assert int(b.get_runtime()[2]) == fi and b.get_iterations_run() == o.iterations_run()
+    c = ShardedSVGDICP(prm, init, device_index=0); c.add_cloud(src, tgt, init); c.set_initial_mean(np.eye(4)); c.stein_align()
+    assert int(c.get_runtime()[2]) == fi and c.get_iterations_run() == o.iterations_run()
+    assert np.allclose(c.get_particles(), o.get_particles(), rtol=0, atol=TIGHT)
+    # no stop: the constructor's value stays (SVGDICP.cpp:42)
+    prm2 = hip.SteinICPParam(iterations=3, lr=0.01, max_dist=1.0, check_early_stop=True, convergence_threshold=1e-9, KNN_count=16,
+                             optimizer="Adam")
+    o2 = orc.Solver(init, mode=orc.MODE_SVGD, svn_full_grad=False, **dict(cfg, iterations=3, convergence_threshold=1e-9))
+    o2.add_cloud(src, tgt, init); o2.stein_align()
+    assert o2.iterations_run() == 3
+    e = hip.SVGDICP(prm2, init); e.add_cloud(src, tgt, init); e.stein_align()
+    assert int(e.get_runtime()[2]) == o2.finish_iter()   # constructor value: no stop
 
 
 def test_hip_svgd_stale_pose_quirk_and_no_optimizer(hip, orc):
@@ -314,8 +372,16 @@ def test_stage_b_f32_search_is_bit_identical_to_f64_kernel(hip, P, full, K):
     for mode in ("valu", "mfma"):                                  # same tiling as the f64 kernel: same summation order
         assert np.array_equal(out["f64"][2], out[mode][2]), mode
         assert np.array_equal(out["f64"][0], out[mode][0]), mode
-    # the split variant partitions the source points differently (no LDS tiles): same terms, other order
-    np.testing.assert_allclose(out["split"][2], out["f64"][2], rtol=1e-12, atol=1e-9)
+    # the split variant partitions the source points differently (no LDS tiles) and its accumulate kernel forms Ts, d² and the
+    # weight with fused operations and hand-refined rsq / rcp (stein_split.hip): same terms to a few 2^-52, other order.
+    # The RAW sums must agree to 1e-12 — they are the H entries that finalize_Hb copies (Σw, ±Σw·s, −Σw·s_i·s_j, i != j);
+    # the diagonal of the rotation block is a difference of sums (tr − xx: cancellation by up to |s|²/|s_perp|²) and gets the
+    # oracle comparisons' 1e-11
+    Hs, Hf = out["split"][2].reshape(-1, 6, 6), out["f64"][2].reshape(-1, 6, 6)
+    raw = [(0, 0), (0, 4), (0, 5), (1, 5), (3, 4), (3, 5), (4, 5)]
+    for (i, j) in raw:
+        np.testing.assert_allclose(Hs[:, i, j], Hf[:, i, j], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(Hs, Hf, rtol=1e-11, atol=1e-9)
     np.testing.assert_allclose(out["split"][0], out["f64"][0], rtol=0, atol=1e-9)
 
 
@@ -514,7 +580,7 @@ def _two_rank_worker(rank, world, port, out_dir):
     src, tgt = pkg.scans.random_clouds(B, M, seed=23, extent=25.0)
     init = pkg.scans.make_particles(P, seed=23) * 0.3
     prm = pkg.SteinICPParam(iterations=5, lr=1.0, max_dist=1.0, KNN_count=40, SVN_full_grad=True)
-    s = ShardedSVNICP(prm, init, device_index=0)
+    s = ShardedSVNICP(prm, init, device_index=0, split="particles")
     s.add_cloud(src, tgt, init); s.set_initial_mean(np.eye(4)); s.stein_align()
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), particles=s.get_particles(), cov=s.get_cov_matrix(),
              cand=s.get_candidates())
@@ -540,6 +606,109 @@ def test_two_processes_one_gpu_sharded_driver(hip, tmp_path):
     assert np.allclose(r0["particles"], ref.get_particles(), rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("W,mode", [(2, "svn"), (3, "svn"), (2, "svgd")])
+def test_row_shard_contexts_equal_single_context(hip, W, mode):
+    """Source-row sharding through the C ABI (svnicp_set_row_shard): W contexts on one GPU play W ranks, each is handed only
+    its rows of the source scan; the per-iteration 'all-gather' of the W x P x 22 partial records is a device copy.  The
+    replicas must agree bit for bit; against the one-shot run the sums are grouped differently (1e-12)."""
+    import torch
+    from svnicp_amd.sharded import _DevView, shard_range
+    L = hip.load_library()
+    P, B, M, K, I = 70, 2501, 6000, 40, 5
+    src, tgt = hip.scans.random_clouds(B, M, seed=9)
+    init = hip.scans.make_particles(P, seed=9) * 0.3
+    svgd = mode == "svgd"
+    prm = hip.SteinICPParam(iterations=I, lr=0.01 if svgd else 1.0, max_dist=1.0, KNN_count=K, SVN_full_grad=False, optimizer="Adam")
+    mk = (lambda: hip.SVGDICP(prm, init)) if svgd else (lambda: hip.SVNICP(prm, init))
+    ref = mk(); ref.add_cloud(src, tgt, init); ref.stein_align()
+    ranks = []
+    for r in range(W):
+        lo, hi = shard_range(B, W, r)
+        s = mk(); s.add_cloud(np.ascontiguousarray(src[lo:hi]), tgt, init)
+        assert L.svnicp_set_row_shard(s.handle, r, W, B) == 0
+        assert L.svnicp_align(s.handle) < 0, "the one-shot entry point must refuse a row shard"
+        assert L.svnicp_align_begin(s.handle) == 0
+        assert L.svnicp_stage_candidates(s.handle, 0, hi - lo) == 0
+        assert L.svnicp_build_candidate_table(s.handle) == 0
+        assert np.array_equal(s.get_candidates(), ref.get_candidates()[lo:hi])
+        ranks.append(s)
+    views = [torch.as_tensor(_DevView(L.svnicp_rank_sums_devptr(s.handle), (W, P, 22), "<f8"), device="cuda") for s in ranks]
+    for it in range(I):
+        for s in ranks:
+            assert L.svnicp_iter_accumulate(s.handle, it) == 0
+            L.svnicp_synchronize(s.handle)
+        for r in range(W):            # all-gather: slot r of every context <- rank r's own slot
+            for q in range(W):
+                if q != r:
+                    views[q][r].copy_(views[r][r])
+        torch.cuda.synchronize()
+        for s in ranks:
+            assert L.svnicp_iter_update(s.handle, it) == 0
+    for s in ranks:
+        assert L.svnicp_finish(s.handle) == 0
+        L.svnicp_synchronize(s.handle)
+        assert np.array_equal(s.get_particles(), ranks[0].get_particles())
+        assert np.array_equal(s.get_cov_matrix(), ranks[0].get_cov_matrix())
+        assert np.allclose(s.get_particles(), ref.get_particles(), rtol=0, atol=1e-12)
+        assert np.allclose(s.get_cov_matrix(), ref.get_cov_matrix(), rtol=0, atol=1e-12)
+    # back to one rank: the same context runs the one-shot registration again
+    s = ranks[0]
+    s.add_cloud(src, tgt, init)
+    assert L.svnicp_set_row_shard(s.handle, 0, 1, 0) == 0
+    assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+    if not svgd:   # (SVGD keeps pose_particles_ across registrations: the second run starts elsewhere)
+        assert np.array_equal(s.get_particles(), ref.get_particles())
+
+
+def _two_rank_rows_worker(rank, world, port, out_dir, mode):
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as graft
+    import torch.distributed as dist
+    pkg = graft.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from svnicp_amd.sharded import ShardedSVGDICP, ShardedSVNICP
+    P, B, M = 150, 2001, 9000          # P > 128: the workgroup-parallel Stein step on every rank; ragged row shards
+    src, tgt = pkg.scans.random_clouds(B, M, seed=29, extent=25.0)
+    init = pkg.scans.make_particles(P, seed=29) * 0.3
+    svgd = mode == "svgd"
+    prm = pkg.SteinICPParam(iterations=6, lr=0.01 if svgd else 1.0, max_dist=1.0, KNN_count=24, optimizer="Adam", SVN_full_grad=not svgd)
+    s = (ShardedSVGDICP if svgd else ShardedSVNICP)(prm, init, device_index=0, split="rows")
+    assert (s.Wp, s.Wb) == (1, world)
+    s.add_cloud(src, tgt, init); s.set_initial_mean(np.eye(4)); s.stein_align()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), particles=s.get_particles(), cov=s.get_cov_matrix(), cand=s.get_candidates())
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["svn", "svgd"])
+def test_two_processes_one_gpu_row_sharded(hip, orc, tmp_path, mode):
+    """The row-sharded driver (ShardedSVNICP / ShardedSVGDICP, split="rows") with two ranks on cuda:0 over gloo: each rank
+    uploads only its half of the source scan; replicas bit-identical, equal to the single-process run to 1e-12 and to the
+    oracle to 1e-9."""
+    import socket
+    import torch.multiprocessing as mp
+    from svnicp_amd.sharded import shard_range
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.start_processes(_two_rank_rows_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = (np.load(str(tmp_path / f"r{r}.npz")) for r in range(2))
+    assert np.array_equal(r0["particles"], r1["particles"]) and np.array_equal(r0["cov"], r1["cov"])
+    P, B, M = 150, 2001, 9000
+    src, tgt = hip.scans.random_clouds(B, M, seed=29, extent=25.0)
+    init = hip.scans.make_particles(P, seed=29) * 0.3
+    svgd = mode == "svgd"
+    prm = hip.SteinICPParam(iterations=6, lr=0.01 if svgd else 1.0, max_dist=1.0, KNN_count=24, optimizer="Adam", SVN_full_grad=not svgd)
+    ref = (hip.SVGDICP if svgd else hip.SVNICP)(prm, init); ref.add_cloud(src, tgt, init); ref.stein_align()
+    lo, hi = shard_range(B, 2, 1)
+    assert np.array_equal(r1["cand"], ref.get_candidates()[lo:hi])
+    assert np.allclose(r0["particles"], ref.get_particles(), rtol=0, atol=1e-12)
+    o = orc.Solver(init, mode=orc.MODE_SVGD if svgd else orc.MODE_SVN, iterations=6, lr=prm.lr, max_dist=1.0, knn_count=24,
+                   svn_full_grad=not svgd, optimizer="Adam")
+    o.add_cloud(src, tgt, init); o.stein_align()
+    assert np.allclose(r0["particles"], o.get_particles(), rtol=0, atol=TIGHT)
+
+
 def _two_rank_svgd_worker(rank, world, port, out_dir):
     import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -554,7 +723,7 @@ def _two_rank_svgd_worker(rank, world, port, out_dir):
     src, tgt = pkg.scans.random_clouds(B, M, seed=29, extent=25.0)
     init = pkg.scans.make_particles(P, seed=29) * 0.3
     prm = pkg.SteinICPParam(iterations=6, lr=0.01, max_dist=1.0, KNN_count=24, optimizer="Adam")
-    s = ShardedSVGDICP(prm, init, device_index=0)
+    s = ShardedSVGDICP(prm, init, device_index=0, split="particles")
     s.add_cloud(src, tgt, init); s.set_initial_mean(np.eye(4)); s.stein_align()
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), particles=s.get_particles(), cov=s.get_cov_matrix())
     dist.barrier(); dist.destroy_process_group()
@@ -579,7 +748,7 @@ def test_two_processes_one_gpu_sharded_svgd(hip, orc, tmp_path):
     assert np.allclose(r0["particles"], o.get_particles(), rtol=0, atol=TIGHT)
 
 
-def _two_rank_nccl_worker(rank, world, port, out_dir):
+def _two_rank_nccl_worker(rank, world, port, out_dir, split):
     import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -595,16 +764,17 @@ def _two_rank_nccl_worker(rank, world, port, out_dir):
     src, tgt = pkg.scans.random_clouds(B, M, seed=23, extent=25.0)
     init = pkg.scans.make_particles(P, seed=23) * 0.3
     prm = pkg.SteinICPParam(iterations=5, lr=1.0, max_dist=1.0, KNN_count=40, SVN_full_grad=True)
-    s = ShardedSVNICP(prm, init, device_index=rank)
+    s = ShardedSVNICP(prm, init, device_index=rank, split=split)
     s.add_cloud(src, tgt, init); s.set_initial_mean(np.eye(4)); s.stein_align()
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), particles=s.get_particles(), cov=s.get_cov_matrix(),
              cand=s.get_candidates())
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_two_gpus_rccl_sharded_driver(hip, tmp_path):
+@pytest.mark.parametrize("split", ["rows", "particles"])
+def test_two_gpus_rccl_sharded_driver(hip, tmp_path, split):
     """The RCCL branch of the sharded driver (in-place all-gathers into library-owned device memory through
-    __cuda_array_interface__) on two real GPUs: replicas bit-identical, equal to the single-process run.
+    __cuda_array_interface__) on two real GPUs, both splits: replicas bit-identical, equal to the single-process run.
     Skipped on a one-GPU box — the driver's multi-GPU node runs it."""
     import socket
     import torch
@@ -612,7 +782,7 @@ def test_two_gpus_rccl_sharded_driver(hip, tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    mp.start_processes(_two_rank_nccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_two_rank_nccl_worker, args=(2, port, str(tmp_path), split), nprocs=2, join=True, start_method="spawn")
     r0, r1 = (np.load(str(tmp_path / f"r{r}.npz")) for r in range(2))
     assert np.array_equal(r0["particles"], r1["particles"]) and np.array_equal(r0["cov"], r1["cov"])
     P, B, M = 37, 3001, 20000
@@ -620,8 +790,83 @@ def test_two_gpus_rccl_sharded_driver(hip, tmp_path):
     init = hip.scans.make_particles(P, seed=23) * 0.3
     ref = hip.SVNICP(hip.SteinICPParam(iterations=5, lr=1.0, max_dist=1.0, KNN_count=40, SVN_full_grad=True), init)
     ref.add_cloud(src, tgt, init); ref.stein_align()
-    assert np.array_equal(r0["cand"], ref.get_candidates())
+    rows = slice(0, (B + 1) // 2) if split == "rows" else slice(0, B)     # rank 0 holds only its rows when they are sharded
+    assert np.array_equal(r0["cand"], ref.get_candidates()[rows])
     assert np.allclose(r0["particles"], ref.get_particles(), rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ the C++ RCCL host
+def _write_case(path, src, tgt, init, iterations, knn, full, es, lr, max_dist, thr):
+    import struct
+    B, M, P = src.shape[0], tgt.shape[0], init.shape[1]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<qq", B, M)); f.write(struct.pack("<iiiii", P, iterations, knn, int(full), int(es)))
+        f.write(struct.pack("<ddd", lr, max_dist, thr))
+        f.write(np.ascontiguousarray(src, np.float64).tobytes()); f.write(np.ascontiguousarray(tgt, np.float64).tobytes())
+        f.write(np.ascontiguousarray(init, np.float64).tobytes())
+
+
+def _read_result(path, P, knn):
+    raw = open(path, "rb").read()
+    state, iters = np.frombuffer(raw, np.int32, 2, 0)
+    off = 8
+    mean = np.frombuffer(raw, np.float64, 6, off); off += 48
+    cov = np.frombuffer(raw, np.float64, 36, off); off += 288
+    part = np.frombuffer(raw, np.float64, 6 * P, off); off += 48 * P
+    rows = int(np.frombuffer(raw, np.int64, 1, off)[0]); off += 8
+    cand = np.frombuffer(raw, np.int32, rows * knn, off).reshape(rows, knn)
+    return int(state), int(iters), mean, cov, part, cand
+
+
+@pytest.mark.parametrize("split,mode", [("rows", "svn"), ("particles", "svn"), ("rows", "svgd")])
+def test_cpp_rccl_host_world1(hip, tmp_path, split, mode):
+    """svn-icp_amd/host/sharded_drive (C++: svnicp::Sharded<> on the split-phase C ABI, ncclCommInitRank, ncclAllGather on the
+    library's stream) as a single rank: the split-phase sequence must give the bits of the one-shot svnicp_align."""
+    import subprocess
+    import __graft_entry__ as graft
+    exe = graft.build_cpp_host()
+    P, B, M, K, I = 40, 3000, 9000, 24, 6
+    src, tgt = hip.scans.random_clouds(B, M, seed=61, extent=25.0)
+    init = hip.scans.make_particles(P, seed=61) * 0.3
+    svgd = mode == "svgd"
+    lr = 0.01 if svgd else 1.0
+    _write_case(str(tmp_path / "case.bin"), src, tgt, init, I, K, False, True, lr, 1.0, 1e-7)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([exe, str(tmp_path / "case.bin"), str(tmp_path / "out.bin"), split, mode], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    state, iters, mean, cov, part, cand = _read_result(str(tmp_path / "out.bin"), P, K)
+    prm = hip.SteinICPParam(iterations=I, lr=lr, max_dist=1.0, KNN_count=K, SVN_full_grad=False, check_early_stop=True,
+                            convergence_threshold=1e-7, optimizer="Adam")
+    ref = (hip.SVGDICP if svgd else hip.SVNICP)(prm, init); ref.add_cloud(src, tgt, init)
+    assert ref.stein_align() == state == hip.SteinICPState.ALIGN_SUCCESS
+    assert iters == ref.get_iterations_run()
+    assert np.array_equal(cand, ref.get_candidates())
+    assert np.array_equal(part, ref.get_particles().ravel())
+    assert np.array_equal(mean, ref.get_transformation()) and np.array_equal(cov, ref.get_cov_matrix().ravel())
+
+
+@pytest.mark.parametrize("split", ["rows", "particles"])
+def test_cpp_rccl_host_two_gpus(hip, tmp_path, split):
+    """Two ranks of the C++ host on two GPUs (ncclUniqueId through a file): replicas bit-identical, the single-process result
+    to 1e-12.  Skipped on a one-GPU box (RCCL refuses two ranks on one device)."""
+    import subprocess
+    import torch
+    import __graft_entry__ as graft
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    exe = graft.build_cpp_host()
+    P, B, M, K, I = 40, 3000, 9000, 24, 6
+    src, tgt = hip.scans.random_clouds(B, M, seed=61, extent=25.0)
+    init = hip.scans.make_particles(P, seed=61) * 0.3
+    _write_case(str(tmp_path / "case.bin"), src, tgt, init, I, K, True, False, 1.0, 1.0, 1e-5)
+    procs = [subprocess.Popen([exe, str(tmp_path / "case.bin"), str(tmp_path / f"out{r}.bin"), split, "svn", str(tmp_path / "nccl.id")],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))) for r in range(2)]
+    assert [p.wait(timeout=300) for p in procs] == [0, 0]
+    res = [_read_result(str(tmp_path / f"out{r}.bin"), P, K) for r in range(2)]
+    assert np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][3], res[1][3])
+    ref = hip.SVNICP(hip.SteinICPParam(iterations=I, lr=1.0, max_dist=1.0, KNN_count=K, SVN_full_grad=True), init)
+    ref.add_cloud(src, tgt, init); ref.stein_align()
+    assert np.allclose(res[0][4], ref.get_particles().ravel(), rtol=0, atol=1e-12)
 
 
 # ------------------------------------------------------------------ BASELINE sizes

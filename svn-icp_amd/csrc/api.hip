@@ -42,6 +42,11 @@ struct svnicp_ctx {
   int device = 0;
   int num_cus = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  // second queue: the pair statistics of the Stein step (they need the poses only) run here, beside the stage-B kernels of
+  // the same iteration; forked from and joined into `stream` with events, so the caller still sees one ordered queue
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool median_pending = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   std::string err;
 
@@ -200,6 +205,12 @@ int svnicp_create(const svnicp_params* params, int device, const double* init_po
     return fail(nullptr, SVNICP_ERR_HIP, "svnicp_create: hipStreamCreate failed");
   }
   c->stream = c->own_stream;
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    svnicp_destroy(c);
+    return fail(nullptr, SVNICP_ERR_HIP, "svnicp_create: hipStreamCreate / hipEventCreate failed");
+  }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(nullptr, SVNICP_ERR_HIP, "hipEventCreate failed"); }
   if (c->ctl.ensure(4) != hipSuccess) { delete c; return fail(nullptr, SVNICP_ERR_NOMEM, "hipMalloc failed"); }
@@ -228,6 +239,9 @@ void svnicp_destroy(svnicp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   DevBuf<double>* dbl[] = {&c->src, &c->tgt, &c->tx, &c->ty, &c->tz, &c->pool_d, &c->cand_d2, &c->table,
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
@@ -524,6 +538,9 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->trh.p, 0, ((size_t)I + 1) * 8, c->stream));
   }
   c->pused = 0;
+  if (c->median_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // a registration that was abandoned between its two per-iteration calls
+  c->median_pending = false;
+  HIPCHK(c, hipMemsetAsync(c->uctl.p, 0, update_uctl_doubles(P) * sizeof(double), c->stream));   // tickets, counters, pair histogram
   if (!c->finish_seen && c->prm.mode == SVNICP_MODE_SVGD && c->prm.check_early_stop) {
     // finish_iter_ is sticky across registrations (SVGDICP.cpp:42,128): fold the previous registration's stop flag in before
     // the control words are reset, in case nobody asked for svnicp_get_runtime in between (SVGD mode with early stop only)
@@ -672,14 +689,52 @@ int svnicp_build_candidate_table(svnicp_ctx* c) {
   return SVNICP_OK;
 }
 
+// argument block of the Stein-step kernels for iteration `it`
+static UpdateArgs update_args(svnicp_ctx* c, int it) {
+  UpdateArgs u{};
+  u.sums = c->row_world > 1 ? c->rank_sums.p : c->sums.p; u.n_ranks = c->row_world; u.R = c->R.p; u.t = c->t.p; u.Rtot = c->Rtot.p; u.pose = c->pose0;
+  u.P = c->P; u.iteration = it; u.iterations = c->prm.iterations;
+  u.lr = c->prm.lr; u.conv_thr = c->prm.convergence_threshold;
+  u.check_early_stop = c->prm.check_early_stop; u.full_grad = c->prm.svn_full_grad;
+  u.work = c->work.p; u.history = c->history.p; u.pose_out = c->pose_out.p; u.ctl = c->ctl.p;
+  if (c->prm.record_trace) {
+    u.trH = c->trH.p + (size_t)it * c->P * 36; u.trb = c->trb.p + (size_t)it * c->P * 6;
+    u.trN = c->trN.p + (size_t)it * c->P * 6; u.trphi = c->trphi.p + (size_t)it * c->P * 6; u.trh = c->trh.p + it;
+  }
+  u.eul = c->eul.p; u.opt = c->opt.p; u.optimizer = c->prm.optimizer;
+  u.n_src = (double)(c->row_world > 1 ? c->B_total : c->B);   // gradient_scaling_factor_ = the whole scan's size (SVGDICP.cpp:58)
+  u.uctl = c->uctl.p;
+  u.dbg = c->tune.debug ? c->dbg_upd : nullptr;
+  u.svgd = c->prm.mode == SVNICP_MODE_SVGD ? 1 : 0;
+  return u;
+}
+// P = 1 (no pair statistics) and option update=fused: the whole Stein step is one one-workgroup kernel on the main stream
+static bool update_one_kernel(const svnicp_ctx* c) { return c->P < 2 || (c->tune.update_fused && c->P <= c->tune.fused_update_max_p); }
+
+// the pair statistics of iteration `it` (bandwidth h from the exact median of the pair distances): they depend on the
+// poses only, so they are forked onto the second stream at the START of the iteration and run beside the search and
+// accumulate kernels; svnicp_iter_update joins before the Stein direction
+static int fork_median(svnicp_ctx* c, int it) {
+  if (update_one_kernel(c) || c->median_pending) return SVNICP_OK;
+  if (c->tune.debug && !c->dbg_upd) { HIPCHK(c, hipMalloc(&c->dbg_upd, 8 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->dbg_upd, 0, 8 * sizeof(unsigned long long))); }
+  const UpdateArgs u = update_args(c, it);
+  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+  HIPCHK(c, launch_update_median(u, c->num_cus, c->tune.fused_update_max_p, c->side));
+  HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+  c->median_pending = true;
+  return SVNICP_OK;
+}
+
 int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   CTX_CHECK(c);
   if (!c->began || !c->have_candidates)
     return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_accumulate: candidates not staged");
   if (it < 0 || it >= c->prm.iterations) return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_accumulate: bad iteration");
+  if (bind(c)) return SVNICP_ERR_HIP;
+  if (const int rc = fork_median(c, it)) return rc;
   const int nshard = c->p_hi - c->p_lo;
   if (nshard <= 0) return SVNICP_OK;
-  if (bind(c)) return SVNICP_ERR_HIP;
   AccumArgs a{};
   a.src = c->src.p; a.table = c->table.p; a.tablef = c->tablef.p; a.tablea = c->tablea.p; a.kbest = c->kbest.p; a.tgt = c->tgt.p; a.cand = c->cand_idx.p; a.anchor = c->anchor.p; a.tail = c->tail.p; a.M = c->M; a.cmax = c->cmaxb.p; a.ambig_count = c->ambig.p;
   a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K;
@@ -723,42 +778,28 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
   if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_update: call svnicp_align_begin first");
   if (it < 0 || it >= c->prm.iterations) return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_update: bad iteration");
   if (bind(c)) return SVNICP_ERR_HIP;
-  UpdateArgs u{};
-  u.sums = c->row_world > 1 ? c->rank_sums.p : c->sums.p; u.n_ranks = c->row_world; u.R = c->R.p; u.t = c->t.p; u.Rtot = c->Rtot.p; u.pose = c->pose0;
-  u.P = c->P; u.iteration = it; u.iterations = c->prm.iterations;
-  u.lr = c->prm.lr; u.conv_thr = c->prm.convergence_threshold;
-  u.check_early_stop = c->prm.check_early_stop; u.full_grad = c->prm.svn_full_grad;
-  u.work = c->work.p; u.history = c->history.p; u.pose_out = c->pose_out.p; u.ctl = c->ctl.p;
-  if (c->prm.record_trace) {
-    u.trH = c->trH.p + (size_t)it * c->P * 36; u.trb = c->trb.p + (size_t)it * c->P * 6;
-    u.trN = c->trN.p + (size_t)it * c->P * 6; u.trphi = c->trphi.p + (size_t)it * c->P * 6; u.trh = c->trh.p + it;
-  }
-  u.eul = c->eul.p; u.opt = c->opt.p; u.optimizer = c->prm.optimizer;
-  u.n_src = (double)(c->row_world > 1 ? c->B_total : c->B);   // gradient_scaling_factor_ = the whole scan's size (SVGDICP.cpp:58)
+  if (c->tune.debug && !c->dbg_upd) { HIPCHK(c, hipMalloc(&c->dbg_upd, 8 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->dbg_upd, 0, 8 * sizeof(unsigned long long))); }
+  UpdateArgs u = update_args(c, it);
   HIPCHK(c, prof_begin(c, KC_UPDATE));
-  u.uctl = c->uctl.p;
-  unsigned long long*& dbg_upd = c->dbg_upd;     // debug option: phase cycles of k_particle_update, printed at finish
-  if (c->tune.debug) {
-    if (!dbg_upd) { HIPCHK(c, hipMalloc(&dbg_upd, 8 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(dbg_upd, 0, 8 * sizeof(unsigned long long))); }
-    u.dbg = dbg_upd;
-    if (it == c->prm.iterations - 1) {
-      unsigned long long h[8];
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      HIPCHK(c, hipMemcpy(h, dbg_upd, sizeof(h), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[svnicp] Stein step thread-0 cycles (summed over launches so far; fused kernel: prepare / median / direction / pose / tail; k_upd_front workgroup 0: state / histogram / bin scan / collect / rank): %llu %llu %llu %llu %llu\n", h[0], h[1], h[2], h[3], h[4]);
-    }
+  if (c->tune.debug && it == c->prm.iterations - 1) {   // debug option: phase cycles of the one-workgroup kernels so far
+    unsigned long long h[8];
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->side));
+    HIPCHK(c, hipMemcpy(h, c->dbg_upd, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[svnicp] Stein step thread-0 cycles (summed over launches so far; fused kernel: prepare / median / direction / pose / tail; k_upd_median: state / histogram / bin scan / collect / rank): %llu %llu %llu %llu %llu\n", h[0], h[1], h[2], h[3], h[4]);
   }
-  u.svgd = 0;
-  if (c->prm.mode == SVNICP_MODE_SVGD) {
-    // one workgroup up to the same particle count as the SVN step; above it the workgroup-parallel chain (its median
-    // select, one wavefront per particle for the Stein direction and the optimizer step)
-    if (c->P > c->tune.fused_update_max_p) { u.svgd = 1; HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream)); }
-    else if (c->P >= 2 && !c->tune.update_fused) { u.svgd = 1; HIPCHK(c, launch_update_front(u, c->stream)); }   // median / gradients / directions on separate workgroups
-    else HIPCHK(c, launch_update_svgd(u, c->stream));
+  if (update_one_kernel(c)) {
+    u.svgd = 0;   // the one-workgroup kernels are per mode
+    if (c->prm.mode == SVNICP_MODE_SVGD) HIPCHK(c, launch_update_svgd(u, c->stream));
+    else HIPCHK(c, launch_update(u, c->stream));
+  } else {
+    // pair statistics: forked at the start of the iteration; a caller that skipped svnicp_iter_accumulate gets them here
+    if (const int rc = fork_median(c, it)) return rc;
+    HIPCHK(c, launch_update_prepare(u, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->median_pending = false;
+    HIPCHK(c, launch_update_direction(u, c->stream));
   }
-  else if (c->P > c->tune.fused_update_max_p) HIPCHK(c, launch_update_multi(u, c->num_cus, c->stream));
-  else if (c->P >= 2 && !c->tune.update_fused) HIPCHK(c, launch_update_front(u, c->stream));  // option "update": fused one-kernel step
-  else HIPCHK(c, launch_update(u, c->stream));
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;
 }

@@ -168,9 +168,6 @@ hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const doubl
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st);
 // q[b] = (s·R^T) + t with the stage-B expression (SVNICP.cpp:62-64); pose12 = device [R row-major | t]
 hipError_t launch_transform_cloud(const double* src, int64_t B, const double* pose12, double* q, const int* ctl, hipStream_t st);
-hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles,
-                                  double* sums, const int* ctl, hipStream_t st);
-
 // ---------------- particle update (particle_update.hip) ----------------
 struct UpdateArgs {
   const double* sums;  // [P][kNSums] (all particles); source-row sharding: [n_ranks][P][kNSums], summed in rank order on load
@@ -202,8 +199,13 @@ hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose
                                  double* Rtot, double* pose_out, int refresh_pose, double* eul, hipStream_t st);
 hipError_t launch_update_svgd(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
-hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st);  // P > 128: workgroup-parallel
-hipError_t launch_update_front(const UpdateArgs& a, hipStream_t st);                // 2 <= P <= 128: one-workgroup front + parallel direction
+// the Stein step of P >= 2 particles in three pieces (particle_update.hip): pair statistics (second stream), sums -> H, b,
+// Newton steps, direction + pose update
+hipError_t launch_update_median(const UpdateArgs& a, int num_cus, int max_p_one_workgroup, hipStream_t st);
+hipError_t launch_update_prepare(const UpdateArgs& a, hipStream_t st);
+hipError_t launch_update_direction(const UpdateArgs& a, hipStream_t st);
+hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles, double* sums, const int* ctl,
+                                  hipStream_t st);
 size_t update_uctl_doubles(int P);
 struct StatsArgs { const double* pose; int P; int mode; double* out; /* mean6,var6,cov36,weightsP */ };
 hipError_t launch_stats(const StatsArgs& a, hipStream_t st);

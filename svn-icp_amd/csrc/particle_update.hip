@@ -432,10 +432,10 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
 // edge bins) locates the bin holding the median and the rank inside it; (2) the keys of that one bin
 // (~0.4 % of the pairs) are collected and an exact radix select runs on them.  Deterministic, no
 // sampling, exact for any input (a degenerate distribution only makes the last select longer).
-// uctl doubles: [2] h  [3..38] Hinv ; as u64: [40] nan flag [41] ticket [42] median bin [43] rank inside
+// uctl doubles: [2] h  [3..38] Hinv ; as u64: [40] nan flag [42] median bin [43] rank inside
 // the bin [44] collected count ; [64 .. 64+P) step norms ; then the global histogram (u32 x HB_NB).
 // ---------------------------------------------------------------------------------------------
-constexpr int UCTL_H = 2, UCTL_HINV = 3, UCTL_NAN = 40, UCTL_TICKET = 41, UCTL_BIN = 42, UCTL_RANK = 43, UCTL_CNT = 44,
+constexpr int UCTL_H = 2, UCTL_HINV = 3, UCTL_NAN = 40, UCTL_BIN = 42, UCTL_RANK = 43, UCTL_CNT = 44,
               UCTL_NORM = 64;
 constexpr int HB_OCT = 48, HB_NB = HB_OCT * 256, HB_EXP0 = 1023 - 40;
 constexpr int SEL_LDS_KEYS = 16384;
@@ -456,51 +456,116 @@ __device__ __forceinline__ double* upd_hpart(double* uctl, int P) {  // [ceil(P/
 __device__ void svgd_gradient(const UpdateArgs& a, int p, double* g6);
 __device__ double svgd_step_one(const UpdateArgs& a, int p, const double* phi6, const double* xold6);
 
-__global__ __launch_bounds__(128) void k_upd_prepare(UpdateArgs a) {
+// ---- the sums-dependent half of the Stein step: k_upd_prepare ----------------------------------------------------------
+// Per particle: H (+1e-6·I), b and the Newton step N = H⁻¹b (SVNICP.cpp:146-162) — in SVGD-ICP mode the first-order
+// gradient goes into the N slot (SVGDICP.cpp:398-455); for the default SVN branch also the mean Hessian (summed in particle
+// order) and its inverse (SVNICP.cpp:85,225).  It needs the sums and nothing else; the other half of the step (the pair
+// statistics: k_upd_median or the k_upd_hist chain) needs the poses and nothing else and runs on a second stream beside the
+// search and accumulate kernels.  Workgroups 0 … ceil(P/64)−1: one particle per lane of wave 0 (a 6x6 LU per lane is a long
+// serial chain: 64 per workgroup spreads it over the chip); the last workgroup: the mean Hessian from ITS OWN finalisation
+// of every particle (no workgroup waits for another) and the inverse.
+// Measured and dropped in round 3: running this as the tail of k_reduce_partials (its last workgroup, one ticket per
+// workgroup) — as one workgroup for all particles 20 us, with one reduce workgroup per particle + a ticketed mean 28 us,
+// against 6 + 8 us for the two launches: a serial tail on one CU costs more than the launch it saves.
+constexpr int PREP_T = 256, PREP_CH = 128, PREP_PW = 64;
+struct PrepShared { double H[PREP_CH][37]; double Hmean[36]; };   // 37.3 KB
+
+__global__ __launch_bounds__(PREP_T) void k_upd_prepare(UpdateArgs a) {
   if (a.ctl[0]) return;
-  __shared__ double sh_H[128 * 37];
-  const int P = a.P;
+  __shared__ PrepShared sh;
+  const int tid = threadIdx.x, P = a.P;
   Work w(a.work, P);
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned int* gh = upd_hist(a.uctl, P);
-  for (int e = p; e < HB_NB; e += gridDim.x * blockDim.x) gh[e] = 0u;
-  if (p == 0) {
-    unsigned long long* u = reinterpret_cast<unsigned long long*>(a.uctl);
-    u[UCTL_NAN] = 0ull; u[UCTL_TICKET] = 0ull; u[UCTL_CNT] = 0ull;
-  }
-  if (a.svgd) {  // SVGD-ICP: the "Newton" slot carries the first-order gradient, x is pose_particles_ as it stands (SVGDICP.cpp:106-110)
-    if (p < P) {
+  const int n_pw = (P + PREP_PW - 1) / PREP_PW;
+  if ((int)blockIdx.x < n_pw) {
+    const int p = blockIdx.x * PREP_PW + tid;
+    if (tid >= PREP_PW || p >= P) return;
+    if (a.svgd) {
       double g6[6];
       svgd_gradient(a, p, g6);
 #pragma unroll
-      for (int d = 0; d < 6; ++d) { w.N[p * 6 + d] = g6[d]; w.x[p * 6 + d] = a.pose_out[d * P + p]; }
+      for (int d = 0; d < 6; ++d) w.N[p * 6 + d] = g6[d];
+      return;
     }
-    return;
-  }
-  if (p < P) {
-    double Rc[9], H[36], b[6], LU[36], x6[6];
+    double Rc[9], H[36], b[6], LU[36], x6[6], sm[kNSums];
     int piv[6];
     mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
-    { double sm[kNSums]; load_sums(a, p, sm); finalize_Hb(sm, Rc, H, b); }
+    load_sums(a, p, sm);
+    finalize_Hb(sm, Rc, H, b);
 #pragma unroll
-    for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; sh_H[threadIdx.x * 37 + i] = H[i]; }
+    for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; }
     const bool ok = lu6(LU, piv);
 #pragma unroll
     for (int i = 0; i < 6; ++i) x6[i] = b[i];
-    lu6_solve(LU, piv, x6);
+    lu6_solve(LU, piv, x6);                                   // SVNICP.cpp:162
 #pragma unroll
     for (int i = 0; i < 6; ++i) { w.b[p * 6 + i] = b[i]; w.N[p * 6 + i] = ok ? x6[i] : __builtin_nan(""); }
-    double lg[3];
-    so3_log(a.R + 9 * p, lg);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { w.x[p * 6 + i] = a.t[3 * p + i]; w.x[p * 6 + 3 + i] = lg[i]; }
+    return;
   }
+  // last workgroup (launched only for the default SVN branch): mean Hessian and its inverse
+  double hsum = 0.0;                   // thread e < 36: Σ_p H_p[e], particle order
+  for (int c0 = 0; c0 < P; c0 += PREP_CH) {
+    const int p = c0 + tid;
+    if (tid < PREP_CH && p < P) {
+      double Rc[9], H[36], b[6], sm[kNSums];
+      mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
+      load_sums(a, p, sm);
+      finalize_Hb(sm, Rc, H, b);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) sh.H[tid][i] = H[i];
+    }
+    __syncthreads();
+    const int cnt = P - c0 < PREP_CH ? P - c0 : PREP_CH;
+    if (tid < 36)
+      for (int q = 0; q < cnt; ++q) hsum += sh.H[q][tid];
+    __syncthreads();
+  }
+  if (tid < 36) sh.Hmean[tid] = hsum / P;                     // mean over particles (SVNICP.cpp:85)
   __syncthreads();
-  if (threadIdx.x < 36) {  // this workgroup's Hessian sum, fixed order (mean Hessian, SVNICP.cpp:85)
-    const int cnt = min(128, P - (int)blockIdx.x * 128);
-    double sacc = 0.0;
-    for (int q = 0; q < cnt; ++q) sacc += sh_H[q * 37 + threadIdx.x];
-    upd_hpart(a.uctl, P)[blockIdx.x * 36 + threadIdx.x] = sacc;
+  if (tid < 6) {                                              // linalg::inv (SVNICP.cpp:225): column tid of the inverse
+    double LU[36], col[6];
+    int piv[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) LU[i] = sh.Hmean[i];
+    const bool ok = lu6(LU, piv);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) col[r] = (r == tid) ? 1.0 : 0.0;
+    lu6_solve(LU, piv, col);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a.uctl[UCTL_HINV + 6 * r + tid] = ok ? col[r] : __builtin_nan("");
+  }
+}
+
+// sums[p_lo + i][s] = Σ_blk partial[blk][i][s], block order fixed.  Workgroup = 16 entries × 16 block lanes; each block
+// lane walks blk = bl, bl+16, … with eight loads in flight and the 16 lanes are folded in order: deterministic, and
+// independent of the launch geometry.
+__global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, int nblk, int Ppad, int p_lo,
+                                                          int n_particles, double* __restrict__ sums, const int* __restrict__ ctl) {
+  if (ctl[0]) return;
+  __shared__ double red[16][17];
+  const int el = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const int entry = blockIdx.x * 16 + el;  // index into [n_particles][kNSums]
+  const int n_entries = n_particles * kNSums;
+  double a = 0.0;
+  if (entry < n_entries) {
+    const size_t stride = (size_t)Ppad * kNSums;
+    const double* src = partial + entry;
+    int blk = bl;
+    for (; blk + 7 * 16 < nblk; blk += 8 * 16) {
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(blk + 16 * i) * stride];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a += v[i];
+    }
+    for (; blk < nblk; blk += 16) a += src[(size_t)blk * stride];
+  }
+  red[bl][el] = a;
+  __syncthreads();
+  if (bl == 0 && entry < n_entries) {
+    double s = red[0][el];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s += red[i][el];
+    sums[(size_t)p_lo * kNSums + entry] = s;
   }
 }
 
@@ -514,7 +579,14 @@ __global__ __launch_bounds__(256) void k_upd_hist(UpdateArgs a) {
   Work w(a.work, P);
   double* lx = dyn;
   unsigned int* lh = reinterpret_cast<unsigned int*>(dyn + 6 * P);
-  for (int e = tid; e < 6 * P; e += 256) lx[e] = w.x[e];
+  // x = pose_particles_ = [t ; Log R] as the last pose update left it (SVNICP.cpp:74-77,103-106; SVGD-ICP: as it stands,
+  // SVGDICP.cpp:106-110) — this chain runs beside the stage-B kernels and must not depend on anything they produce
+  for (int e = tid; e < 6 * P; e += 256) {
+    const int pp = e / 6, d = e - 6 * pp;
+    const double v = a.pose_out[d * P + pp];
+    lx[e] = v;
+    if (blockIdx.x == 0) w.x[e] = v;   // k_upd_direction reads x from here
+  }
   for (int e = tid; e < HB_NB; e += 256) lh[e] = 0u;
   __syncthreads();
   unsigned long long* u = reinterpret_cast<unsigned long long*>(a.uctl);
@@ -554,7 +626,7 @@ __global__ __launch_bounds__(256) void k_upd_collect(UpdateArgs a) {
   Work w(a.work, P);
   double* lx = dyn;
   double* lbuf = dyn + 6 * P;  // [COLL_CHUNK]: matches of one chunk of pairs
-  for (int e = tid; e < 6 * P; e += 256) lx[e] = w.x[e];
+  for (int e = tid; e < 6 * P; e += 256) { const int pp = e / 6, d = e - 6 * pp; lx[e] = a.pose_out[d * P + pp]; }
   if (tid == 0) sh_cnt = 0u;
   unsigned long long* u = reinterpret_cast<unsigned long long*>(a.uctl);
   const int n = P * P;
@@ -656,7 +728,7 @@ __device__ unsigned long long block_select(F key_at, int n, unsigned int rank, i
   return S->prefix;
 }
 
-// exact median inside its bin -> h ; mean Hessian and its inverse (default branch)
+// exact median inside its bin -> h
 __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
   if (a.ctl[0]) return;
   extern __shared__ __align__(16) double dyn[];
@@ -664,32 +736,6 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
   const int P = a.P;
   Work w(a.work, P);
   __shared__ SelShared sel;
-  __shared__ double sh_Hmean[36];
-  if (blockIdx.x == 1) {
-    // second workgroup: mean Hessian from the per-block sums of k_upd_prepare and its inverse (linalg::inv,
-    // SVNICP.cpp:225) — a long serial 6x6 LU that the median select should not wait for
-    if (a.full_grad || a.svgd) return;   // only the default SVN branch preconditions with the mean Hessian
-    if (tid < 36) {
-      const double* hp = upd_hpart(a.uctl, P);
-      double sacc = 0.0;
-      for (int q = 0; q < (P + 127) / 128; ++q) sacc += hp[q * 36 + tid];
-      sh_Hmean[tid] = sacc / P;
-    }
-    __syncthreads();
-    if (tid < 6) {
-      double LU[36], col[6];
-      int piv[6];
-#pragma unroll
-      for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
-      const bool ok = lu6(LU, piv);
-#pragma unroll
-      for (int r2 = 0; r2 < 6; ++r2) col[r2] = (r2 == tid) ? 1.0 : 0.0;
-      lu6_solve(LU, piv, col);
-#pragma unroll
-      for (int r2 = 0; r2 < 6; ++r2) a.uctl[UCTL_HINV + 6 * r2 + tid] = ok ? col[r2] : __builtin_nan("");
-    }
-    return;
-  }
   const unsigned long long* u = reinterpret_cast<const unsigned long long*>(a.uctl);
   const int m = (int)u[UCTL_CNT];
   const unsigned int r = (unsigned int)u[UCTL_RANK];
@@ -713,17 +759,25 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
     const double med = u[UCTL_NAN] ? __builtin_nan("") : __longlong_as_double((long long)kmed);
     a.uctl[UCTL_H] = med / log((double)(P + 1));              // SVNICP.cpp:262
   }
+  // leave the chain's global state as the next iteration's k_upd_hist expects it (svnicp_align_begin zeroes it once)
+  __syncthreads();
+  unsigned int* gh = upd_hist(a.uctl, P);
+  for (int e = tid; e < HB_NB; e += UT) gh[e] = 0u;
+  if (tid == 0) {
+    unsigned long long* uw = reinterpret_cast<unsigned long long*>(a.uctl);
+    uw[UCTL_NAN] = 0ull; uw[UCTL_CNT] = 0ull;
+  }
 }
 
-// Front half of the Stein step for 2 <= P <= 128 in one launch of a few workgroups that do not wait for each other
-// (the pair work is small, a launch is not): workgroup 0 the exact lower median, workgroup 1 the mean Hessian inverse,
-// workgroups 2.. per-particle H, b, Newton step (as k_upd_prepare).  The median: the exact lower median of
-// the P² pair distances through an LDS copy of the log-binned histogram of the k_upd_* chain: bin the keys,
-// find the median's bin, collect that bin (~0.4 % of the keys), rank its keys by counting.  k_upd_direction
-// (one wavefront per particle, pose update fused) then runs on as many CUs as there are particles.
-// Measured (SVNICP_DEBUG stamps): the 8-pass LDS radix select took 60 % of the fused kernel's 63 us.
+// The pair statistics of the Stein step for 2 <= P <= 128, one workgroup: the exact lower median of the P² pair distances
+// (torch::median over all entries incl. the diagonal's zeros, SVNICP.cpp:262) through an LDS copy of the log-binned
+// histogram of the k_upd_* chain — bin the keys, find the median's bin, collect that bin (~0.4 % of the keys), rank its keys
+// by counting — and with it the bandwidth h.  Needs the poses only (x = pose_particles_ = [t ; Log R], which the last pose
+// update left in pose_out), so it is launched on the context's second stream at the START of an iteration and runs beside
+// the search and accumulate kernels; k_upd_direction (one wavefront per particle, pose update fused) waits for it.
+// Measured (debug stamps): the 8-pass LDS radix select took 60 % of the fused kernel's 63 us; this kernel takes 13.5 us.
 constexpr int FRONT_BUF = 2048;  // keys of the median's bin held in LDS (+8 slack for the unrolled ranking); more (degenerate input) -> 8-pass select
-__global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
+__global__ __launch_bounds__(UT) void k_upd_median(UpdateArgs a) {
   if (a.ctl[0]) return;
   extern __shared__ __align__(16) double dyn[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
@@ -733,76 +787,10 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
   double* lbuf = dyn + 6 * P;                                         // [FRONT_BUF]
   unsigned int* lh = reinterpret_cast<unsigned int*>(lbuf + FRONT_BUF + 8);  // [HB_NB]
   __shared__ SelShared sel;
-  __shared__ double sh_Hmean[36];
   __shared__ unsigned int sh_scan[UT];
   __shared__ unsigned int sh_cnt;
   __shared__ int sh_bin, sh_rank, sh_nan;
 
-  if (blockIdx.x == 1) {
-    // second workgroup: mean Hessian (SVNICP.cpp:85) and its inverse (linalg::inv, SVNICP.cpp:225), concurrently
-    // with the median on the first one; the 6x6 LU is a long serial chain that nothing else should wait for
-    if (a.full_grad || a.svgd) return;
-    double* lH = dyn;  // [P][36]
-    for (int p = tid; p < P; p += UT) {
-      double Rc[9], H[36], b[6];
-      mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
-      { double sm[kNSums]; load_sums(a, p, sm); finalize_Hb(sm, Rc, H, b); }
-#pragma unroll
-      for (int i = 0; i < 36; ++i) lH[p * 36 + i] = H[i];
-    }
-    __syncthreads();
-    if (tid < 36 * 8) {
-      const int e = tid >> 3, part = tid & 7;
-      double sacc = 0.0;
-      for (int p = part; p < P; p += 8) sacc += lH[p * 36 + e];
-#pragma unroll
-      for (int off = 4; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 8);
-      if (part == 0) sh_Hmean[e] = sacc / P;
-    }
-    __syncthreads();
-    if (tid < 6) {
-      double LU[36], col[6];
-      int piv[6];
-#pragma unroll
-      for (int i = 0; i < 36; ++i) LU[i] = sh_Hmean[i];
-      const bool ok = lu6(LU, piv);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) col[r] = (r == tid) ? 1.0 : 0.0;
-      lu6_solve(LU, piv, col);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) a.uctl[UCTL_HINV + 6 * r + tid] = ok ? col[r] : __builtin_nan("");
-    }
-    return;
-  }
-  if (blockIdx.x >= 2) {
-    // workgroups 2..: H, b and the Newton step of 64 particles each (SVNICP.cpp:146-162) — a 6x6 LU per thread, a long
-    // serial chain that only k_upd_direction needs; it used to run ahead of the median on workgroup 0 (a third of its time)
-    const int p = (blockIdx.x - 2) * 64 + tid;
-    if (a.svgd) {   // SVGD-ICP: the "Newton" slot carries the first-order gradient (SVGDICP.cpp:106-110), as in k_upd_prepare
-      if (tid < 64 && p < P) {
-        double g6[6];
-        svgd_gradient(a, p, g6);
-#pragma unroll
-        for (int d = 0; d < 6; ++d) w.N[p * 6 + d] = g6[d];
-      }
-      return;
-    }
-    if (tid < 64 && p < P) {
-      double Rc[9], H[36], b[6], LU[36], x6[6];
-      int piv[6];
-      mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
-      { double sm[kNSums]; load_sums(a, p, sm); finalize_Hb(sm, Rc, H, b); }
-#pragma unroll
-      for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; }
-      const bool ok = lu6(LU, piv);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) x6[i] = b[i];
-      lu6_solve(LU, piv, x6);                                   // SVNICP.cpp:162
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { w.b[p * 6 + i] = b[i]; w.N[p * 6 + i] = ok ? x6[i] : __builtin_nan(""); }
-    }
-    return;
-  }
   unsigned long long tdbg = a.dbg ? __builtin_readcyclecounter() : 0ull;
   auto stamp = [&](int i) {   // debug option: thread-0 cycles per phase of the median workgroup
     if (!a.dbg || tid != 0) return;
@@ -812,19 +800,9 @@ __global__ __launch_bounds__(UT) void k_upd_front(UpdateArgs a) {
   };
   for (int e = tid; e < HB_NB; e += UT) lh[e] = 0u;
   if (tid == 0) { sh_cnt = 0u; sh_nan = 0; sh_bin = 0; sh_rank = 0; }
-  for (int p = tid; p < P; p += UT) {
-    if (a.svgd) {   // x is pose_particles_ as it stands (SVGDICP.cpp:106-110)
+  for (int p = tid; p < P; p += UT) {   // x = pose_particles_ (SVNICP.cpp:74-77,103-106; SVGD-ICP: as it stands, SVGDICP.cpp:106-110)
 #pragma unroll
-      for (int d = 0; d < 6; ++d) { const double v = a.pose_out[d * P + p]; lx[p * 6 + d] = v; w.x[p * 6 + d] = v; }
-      continue;
-    }
-    double lg[3];
-    so3_log(a.R + 9 * p, lg);                                 // SVNICP.cpp:74-77
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      lx[p * 6 + i] = a.t[3 * p + i]; lx[p * 6 + 3 + i] = lg[i];
-      w.x[p * 6 + i] = a.t[3 * p + i]; w.x[p * 6 + 3 + i] = lg[i];
-    }
+    for (int d = 0; d < 6; ++d) { const double v = a.pose_out[d * P + p]; lx[p * 6 + d] = v; w.x[p * 6 + d] = v; }
   }
   __syncthreads();
   stamp(0);
@@ -1400,8 +1378,20 @@ hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose
   return hipGetLastError();
 }
 
-hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st) {
+// ---- the Stein step of 2 <= P particles as three pieces (api.hip sequences them) --------------------------------------
+//   launch_update_median     pair statistics -> bandwidth h: needs the poses only; on the context's SECOND stream, beside the
+//                            stage-B kernels of the same iteration
+//   launch_update_prepare    H, b, Newton step, mean-Hessian inverse: needs the sums only
+//   launch_update_direction  Stein direction + pose update per particle [+ k_upd_finish: early stop, traces, history]
+hipError_t launch_update_median(const UpdateArgs& a, int num_cus, int max_p_one_workgroup, hipStream_t st) {
   const int P = a.P;
+  if (P <= max_p_one_workgroup && P <= 128) {   // one workgroup, keys in registers (KREG)
+    const size_t smem = (size_t)P * 6 * sizeof(double) + (size_t)(FRONT_BUF + 8) * sizeof(double) + (size_t)HB_NB * sizeof(unsigned int);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_median), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_upd_median, dim3(1), dim3(UT), smem, st, a);
+    return hipGetLastError();
+  }
   const size_t n = (size_t)P * P;
   const size_t xs = (size_t)P * 6 * sizeof(double);
   // few, fat workgroups: each one merges its LDS histogram into the global one with atomics, and those contend
@@ -1418,25 +1408,29 @@ hipError_t launch_update_multi(const UpdateArgs& a, int num_cus, hipStream_t st)
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sel);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_upd_prepare, dim3((P + 127) / 128), dim3(128), 0, st, a);
   hipLaunchKernelGGL(k_upd_hist, dim3(nb), dim3(256), lds_hist, st, a);
   hipLaunchKernelGGL(k_upd_collect, dim3(nb), dim3(256), lds_coll, st, a);
-  hipLaunchKernelGGL(k_upd_select, dim3(2), dim3(UT), lds_sel, st, a);
-  hipLaunchKernelGGL(k_upd_direction, dim3((P + 3) / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_upd_select, dim3(1), dim3(UT), lds_sel, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_update_prepare(const UpdateArgs& a, hipStream_t st) {
+  const int need_mean = (!a.svgd && !a.full_grad) ? 1 : 0;   // only the default SVN branch preconditions with the mean Hessian
+  hipLaunchKernelGGL(k_upd_prepare, dim3((a.P + PREP_PW - 1) / PREP_PW + need_mean), dim3(PREP_T), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_update_direction(const UpdateArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_upd_direction, dim3((a.P + 3) / 4), dim3(256), 0, st, a);
   if (a.check_early_stop || a.trH) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
-// 2 <= P <= 128: k_upd_front (one workgroup) -> k_upd_direction (one wavefront per particle) [-> k_upd_finish]
-hipError_t launch_update_front(const UpdateArgs& a, hipStream_t st) {
-  const int P = a.P;
-  size_t smem = (size_t)P * 6 * sizeof(double) + (size_t)(FRONT_BUF + 8) * sizeof(double) + (size_t)HB_NB * sizeof(unsigned int);
-  if (smem < (size_t)P * 36 * sizeof(double)) smem = (size_t)P * 36 * sizeof(double);  // second workgroup: H of every particle
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_front), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_upd_front, dim3(2 + (P + 63) / 64), dim3(UT), smem, st, a);
-  hipLaunchKernelGGL(k_upd_direction, dim3((P + 3) / 4), dim3(256), 0, st, a);
-  if (a.check_early_stop || a.trH) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
+hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles, double* sums, const int* ctl,
+                                  hipStream_t st) {
+  const int n_entries = n_particles * kNSums;
+  if (n_entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((n_entries + 15) / 16), dim3(256), 0, st, partial, nblk, Ppad, p_lo, n_particles, sums, ctl);
   return hipGetLastError();
 }
 

@@ -377,41 +377,7 @@ __global__ __launch_bounds__(256) void k_build_table2(const int32_t* __restrict_
   if (lane == 0) cmax[b] = cm;   // NaN coordinates give NaN scores => every step takes the exact path
 }
 
-// sums[p_lo + i][s] = Σ_blk partial[blk][i][s], block order fixed.  Workgroup = 16 entries × 16
-// block lanes; each block lane walks blk = bl, bl+16, … and the 16 lanes are folded in order.
-__global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, int nblk, int Ppad,
-                                                          int p_lo, int n_particles, double* __restrict__ sums,
-                                                          const int* __restrict__ ctl) {
-  if (ctl[0]) return;
-  // 16 entries x 16 block slices per workgroup; every thread sums its blocks in a fixed order with eight loads in
-  // flight, then the 16 slices are added in a fixed order: deterministic, and independent of the launch geometry
-  __shared__ double red[16][17];
-  const int el = threadIdx.x & 15, bl = threadIdx.x >> 4;
-  const int entry = blockIdx.x * 16 + el;  // index into [n_particles][kNSums]
-  const int n_entries = n_particles * kNSums;
-  double a = 0.0;
-  if (entry < n_entries) {
-    const size_t stride = (size_t)Ppad * kNSums;
-    const double* src = partial + entry;
-    int blk = bl;
-    for (; blk + 7 * 16 < nblk; blk += 8 * 16) {
-      double v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(blk + 16 * i) * stride];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a += v[i];
-    }
-    for (; blk < nblk; blk += 16) a += src[(size_t)blk * stride];
-  }
-  red[bl][el] = a;
-  __syncthreads();
-  if (bl == 0 && entry < n_entries) {
-    double s = red[0][el];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) s += red[i][el];
-    sums[(size_t)p_lo * kNSums + entry] = s;
-  }
-}
+// (k_reduce_partials lives in particle_update.hip: its last workgroup goes on with the sums-dependent half of the Stein step)
 
 template <int PW, int WP>
 hipError_t launch_t(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
@@ -538,15 +504,6 @@ hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const doubl
                                float4* tablef, float* cmax, hipStream_t st) {
   if (B <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_build_table2, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, idx, B, K, tgt, M, table, tablef, cmax);
-  return hipGetLastError();
-}
-
-hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles,
-                                  double* sums, const int* ctl, hipStream_t st) {
-  const int n_entries = n_particles * kNSums;
-  if (n_entries <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((n_entries + 15) / 16), dim3(256), 0, st, partial, nblk, Ppad, p_lo,
-                     n_particles, sums, ctl);
   return hipGetLastError();
 }
 

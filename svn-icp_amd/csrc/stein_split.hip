@@ -656,24 +656,25 @@ __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulat
   // J = [R | 0] — the same products are formed here (mf = 0 or 1), which also makes the pair branch-free.
   // `on`: 1.0 for a pair that exists, 0.0 for a point past the block (padding particle lanes are never read back).
   //
-  // Instruction diet of round 3 (this kernel issues ~one f64 instruction per 3.3 cycles per SIMD; 78 -> 63 per pair):
-  //  * the transform and d² are fused multiply-adds (9 + 3 instead of 18 + 5): Ts and d² differ from the search kernel's
-  //    unfused values by one rounding (<= 2^-52 relative); they only feed the mask, the weight and e here;
-  //  * sqrt and the division are v_rsq_f64 / v_rcp_f64 seeds refined by hand.  The seeds are only good to about 2^-13
-  //    relative on this chip (measured, tests/microbench/f64_seed_accuracy.hip; the first version assumed 2^-23 and was
-  //    1.2e-12 off in H), so: root = one coupled Goldschmidt step on (s, h = r/2) — 1.5·2^-26 — then one residual step
-  //    with the refined h — about 2^-51; quotient = two Newton steps, 2^-26 then 2^-52.  The compiler's IEEE sequences
-  //    spend ten more instructions on scaling for denormals, on the last half ulp and on special cases that cannot
-  //    occur here.  The weight is formed as 1 / (1 + (3/d)·|e|) with 3/d rounded once per launch: w agrees with the
-  //    reference's (d / (d + 3|e|))² to a few 2^-52 relative (tests hold the sums to 1e-12 against the f64 kernel);
+  // Instruction diet of round 3 (this kernel issues ~one f64 instruction per 3.3 cycles per SIMD; 78 -> 73 per pair).
+  // Ts and d² keep the search kernel's and the oracle's unfused expressions: the winner was certified for exactly that Ts,
+  // the mask compares exactly that d², and at map-frame coordinates of kilometres one rounding of Ts is 1e-12 m — a fused
+  // transform (nine instructions fewer) was built and moved H by 1e-11 relative there
+  // (test_map_frame_coordinates_far_from_the_origin).  What changed:
+  //  * sqrt and the division are v_rsq_f64 / v_rcp_f64 seeds (2^-24 relative, measured: tests/microbench/
+  //    f64_seed_accuracy.hip) refined by hand: root = one Goldschmidt step on s = x·r with h = r/2 and one residual step,
+  //    quotient = two Newton steps; both come out within 0.5 ulp of the exact value on 4 M inputs (same microbenchmark).
+  //    The compiler's IEEE sequences spend twelve more instructions on scaling for denormals and on special cases that
+  //    cannot occur here.  The weight is formed as 1 / (1 + (3/d)·|e|) with 3/d rounded once per launch: w agrees with
+  //    the reference's (d / (d + 3|e|))² to a few 2^-52 relative (tests hold the raw sums to 1e-12 against the f64 kernel);
   //  * mask·s is not formed: w·(mask·s) = (mask·w)·s exactly, because the mask is 0 or 1.
   const double c3d = 3.0 / a.max_dist;
   auto accumulate = [&](double on, double s0, double s1, double s2, double q0, double q1, double q2) {
-    const double T0 = fma(s2, Rt[2], fma(s1, Rt[1], fma(s0, Rt[0], tt[0])));   // SVNICP.cpp:62-64
-    const double T1 = fma(s2, Rt[5], fma(s1, Rt[4], fma(s0, Rt[3], tt[1])));
-    const double T2 = fma(s2, Rt[8], fma(s1, Rt[7], fma(s0, Rt[6], tt[2])));
+    const double T0 = (s0 * Rt[0] + s1 * Rt[1] + s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64, the search kernel's expression
+    const double T1 = (s0 * Rt[3] + s1 * Rt[4] + s2 * Rt[5]) + tt[1];
+    const double T2 = (s0 * Rt[6] + s1 * Rt[7] + s2 * Rt[8]) + tt[2];
     const double dx = T0 - q0, dy = T1 - q1, dz = T2 - q2;
-    const double best = fma(dx, dx, fma(dy, dy, dz * dz));   // d² of the winner
+    const double best = (dx * dx + dy * dy) + dz * dz;   // exact d² of the winner (knn_cpu.cpp:43-50 order)
     const double mf = best < a.max_dist ? on : 0.0;       // point_filter, SVGDICP.cpp:331-333 (squared distance against max_dist)
     const double x = mf * best;                           // 0 for a rejected row; NaN stays NaN (a non-finite point)
     // |e| = sqrt(x), SVNICP.cpp:120 on the masked rows: rsq seed (x + 2^-1000 keeps x = 0 finite: 0·2^500 = 0), s = x·r,
@@ -681,8 +682,8 @@ __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulat
     const double r0 = __builtin_amdgcn_rsq(x + 0x1p-1000);
     const double sa = x * r0, h0 = 0.5 * r0;
     const double ea = fma(-h0, sa, 0.5);
-    const double sb = fma(sa, ea, sa), hb = fma(h0, ea, h0);
-    const double nn = fma(fma(-sb, sb, x), hb, sb);
+    const double sb = fma(sa, ea, sa);                    // 1.5·2^-48 relative
+    const double nn = fma(fma(-sb, sb, x), h0, sb);       // residual step: h0's 2^-24 is enough here
     // wq = d / (d + 3|e|) = 1 / (1 + (3/d)|e|), SVNICP.cpp:121-122: rcp seed + two Newton steps; exactly 1 for a rejected row
     const double den = fma(c3d, nn, 1.0);
     const double y0 = __builtin_amdgcn_rcp(den);

@@ -17,8 +17,8 @@ __global__ void k(const double* x, double* rsq, double* rcp, double* root, doubl
     const double r0 = __builtin_amdgcn_rsq(v + 0x1p-1000);
     const double sa = v * r0, h0 = 0.5 * r0;
     const double ea = fma(-h0, sa, 0.5);
-    const double sb = fma(sa, ea, sa), hb = fma(h0, ea, h0);
-    root[i] = fma(fma(-sb, sb, v), hb, sb);
+    const double sb = fma(sa, ea, sa);
+    root[i] = fma(fma(-sb, sb, v), h0, sb);
   }
   {  // the kernel's refined reciprocal
     const double y0 = __builtin_amdgcn_rcp(v);

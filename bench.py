@@ -26,7 +26,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   library's stream; roofline_hbm is the HBM view of the same kernel,
   cpu_baseline  — the CPU oracle ("port": oracle/svnicp_oracle.c, OpenMP) timed on this box's host
                   cores on the same workload (rank 0, N = 1 only),
-  svn_full_grad — the same registration with SVNFullGrad = true (BASELINE.md §2 reports both branches).
+  svn_full_grad — the same registration with SVNFullGrad = true (BASELINE.md §2 reports both branches),
+  svgd_adam     — SVGD-ICP (Adam, lr 0.01) on the same clouds; c4_one_gpu — 512 particles on one GPU.
+The timed region carries no profiling hooks; the roofline block comes from a second pass over the same K steps with
+every kernel launch bracketed by hipEvents on the library's stream.
 """
 from __future__ import annotations
 
@@ -305,6 +308,13 @@ def main():
         e2 = time_steps(st2, nside, 1, dist, torch, dev)
         out["svn_full_grad" if not a.full_grad else "svn_default_grad"] = {"registrations_per_s": nside / e2, "ms_per_step": 1e3 * e2 / nside}
         s2.close()
+        # the first-order sibling (SVGD-ICP, Adam, lr 0.01) on the same clouds, so that the driver's N = 1 line times it too
+        sg = pkg.SVGDICP(pkg.SteinICPParam(iterations=I, lr=0.01, max_dist=1.0, KNN_count=K, check_early_stop=False, optimizer="Adam"),
+                         init, device=local_rank)
+        stg = make_step(sg, init); stg()
+        eg = time_steps(stg, nside, 1, dist, torch, dev)
+        out["svgd_adam"] = {"workload": f"SVGD-ICP (Adam, lr 0.01), {P} particles, C3 clouds", "registrations_per_s": nside / eg, "ms_per_step": 1e3 * eg / nside}
+        sg.close()
         c4 = scans.CONFIGS["C4"]
         init4 = scans.make_particles(c4["P"])
         s4 = pkg.SVNICP(prm, init4, pkg.ParticleWeightOpt(), device=local_rank)

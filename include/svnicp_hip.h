@@ -179,6 +179,9 @@ int svnicp_map_size(svnicp_map *map, int64_t *voxels);        /* VoxelHashMap::S
  * xyz: n x 3 float32 (pcl::PointXYZ) in the sensor frame, host or device; pose = rotation (row-major) + translation */
 int svnicp_map_add_cloud(svnicp_map *map, const float *xyz, int64_t n, int mem_kind, const double R_rowmajor[9],
                          const double t[3]);
+/* points svnicp_map_add_cloud has not stored since creation / clear because they lie outside +-2^20 voxels or are NaN
+ * (the reference would index a voxel for them; here they are counted and the call still succeeds) */
+int svnicp_map_skipped_points(svnicp_map *map, int64_t *out);
 /* VoxelHashMap::GetMap(pose, max_range) — VoxelHashMap.cpp:48-58; center NULL or max_range < 0: GetMap() (:44-46).
  * The points are written as float64 [count][3] rows into a device buffer owned by the map (valid until the next query),
  * voxels in ascending (x, y, z) index, points of a voxel in insertion order. */
@@ -229,8 +232,12 @@ int svnicp_get_kernel_ms(svnicp_ctx *ctx, double *ms6, int32_t *launches6);
 
 /* ---- per-scan pre-processing on the device ------------------------------------------------
  * What OdometryPipeline::ICP_processing does to a scan before the solver sees it (src/core/OdometryPipeline.cpp):
- * crop_pointcloud (:692-704), pcl::UniformSampling at 0.5 * voxel_size for the local map (:559, :684-690) and at
- * 1.5 * voxel_size of that cloud for the solver (:560).  The raw float32 scan is uploaded once; the three clouds stay in
+ * crop_pointcloud (:692-704), pcl::UniformSampling at 0.5 * voxel_size (:559, :684-690) and at 1.5 * voxel_size of that
+ * cloud (:560).  Mind the reference's aliasing: downsample_uniform filters the cloud it is handed IN PLACE
+ * (uniform_sampling_.filter(*cloud) on its own input, :684-690), so after :559 *cropped_cloud holds the 0.5-voxel sampling
+ * and after :560 *voxelized_cloud_toMap holds the 1.5-voxel one: the map is SEEDED with the 0.5-voxel cloud (:585,
+ * svnicp_prep_map_cloud_devptr) and UPDATED with the 1.5-voxel cloud (:630, svnicp_prep_source_f32_devptr) — the same
+ * points the solver registers.  The raw float32 scan is uploaded once; the three clouds stay in
  * device memory for svnicp_map_add_cloud(..., SVNICP_MEM_DEVICE) and svnicp_set_source(..., SVNICP_MEM_DEVICE).
  * Leaves are emitted in ascending linear index, the point closest to a leaf centre survives, first in input order on
  * ties (svn-icp_amd/host/registration_pipeline.hpp: downsample_uniform).  scan_max_range: in/out, the largest SQUARED
@@ -243,7 +250,8 @@ int svnicp_prep_scan(svnicp_prep *prep, const float *xyz, int64_t n, int mem_kin
                      double voxel_size, double *scan_max_range, int64_t *n_cropped, int64_t *n_map, int64_t *n_source);
 const float *svnicp_prep_cropped_devptr(svnicp_prep *prep);    /* float32 [n_cropped][3] */
 const float *svnicp_prep_map_cloud_devptr(svnicp_prep *prep);  /* float32 [n_map][3]     */
-const double *svnicp_prep_source_devptr(svnicp_prep *prep);    /* float64 [n_source][3]  */
+const double *svnicp_prep_source_devptr(svnicp_prep *prep);    /* float64 [n_source][3]: the solver's source cloud */
+const float *svnicp_prep_source_f32_devptr(svnicp_prep *prep); /* the same points as float32 rows: what the map is UPDATED with */
 int svnicp_prep_download(svnicp_prep *prep, int which /* 0 cropped, 1 map cloud, 2 source */, float *out_xyz,
                          int64_t cap_points, int64_t *n_out);   /* test tap */
 

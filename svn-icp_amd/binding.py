@@ -90,7 +90,8 @@ def load_library():
     L.svnicp_prep_last_error.restype = C.c_char_p
     L.svnicp_prep_scan.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, dp, C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-    for name in ("svnicp_prep_cropped_devptr", "svnicp_prep_map_cloud_devptr", "svnicp_prep_source_devptr"):
+    L.svnicp_map_skipped_points.argtypes = [vp, C.POINTER(C.c_int64)]
+    for name in ("svnicp_prep_cropped_devptr", "svnicp_prep_map_cloud_devptr", "svnicp_prep_source_devptr", "svnicp_prep_source_f32_devptr"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = vp
     L.svnicp_prep_download.argtypes = [vp, C.c_int, vp, C.c_int64, C.POINTER(C.c_int64)]

@@ -79,6 +79,9 @@ struct svnicp_ctx {
   int accum_mode = 3;  // 0 f64 baseline, 1 f32 VALU search, 2 fused f32 MFMA search, 3 MFMA search + accumulate kernels
   DevBuf<unsigned long long> emax;
   DevBuf<int> fail_count;
+  // correspondence = full reuses fail_list / fail_count for every per-particle search: stage A's own are kept here
+  DevBuf<int> stage_fail_count;
+  DevBuf<int32_t> stage_fail_list;
   // stage A variant: 0 = streaming only (knn_topk), 1 = seeded f32 scan (knn_scan), 2 = pruned tiles (knn_tiles)
   int knn_variant = 0;
   int target_layout = -1;  // what the SoA currently holds: 0 hashed order, 1 Morton tiles, -1 nothing
@@ -215,7 +218,7 @@ int svnicp_create(const svnicp_params* params, int device, const double* init_po
     if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(nullptr, SVNICP_ERR_HIP, "hipEventCreate failed"); }
   if (c->ctl.ensure(4) != hipSuccess) { delete c; return fail(nullptr, SVNICP_ERR_NOMEM, "hipMalloc failed"); }
   *out = c;
-  if (const char* e = getenv("SVNICP_OPTIONS")) {   // read ONCE, at creation: "name=value,name=value" for profiling scripts
+  if (const char* e = getenv("SVNICP_OPTIONS")) {   // read ONCE, at creation: "name=value;name=value" for profiling scripts
     std::string all(e);
     size_t pos = 0;
     while (pos < all.size()) {
@@ -246,7 +249,7 @@ void svnicp_destroy(svnicp_ctx* c) {
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
   for (auto* b : dbl) b->release();
-  c->eul.release(); c->opt.release(); c->uctl.release(); c->rank_sums.release();
+  c->eul.release(); c->opt.release(); c->uctl.release(); c->rank_sums.release(); c->stage_fail_count.release(); c->stage_fail_list.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
   c->full_q.release(); c->full_d2.release(); c->full_idx.release(); c->arena.release(); c->chunk_tab.release();
   c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->tail.release(); c->kbest.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
@@ -668,6 +671,11 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
   HIPCHK(c, prof_begin(c, KC_KNN));
   const int rc = stage_a(c, c->src.p, c->pose0, c->K, c->cand_idx.p, c->cand_d2.p, b_lo, b_hi);
   if (rc) return rc;
+  if (c->tune.full_corr && c->knn_variant != 0) {   // svnicp_get_knn_fallbacks / _rows describe STAGE A, not the last particle's K = 1 search
+    HIPCHK(c, c->stage_fail_count.ensure(1)); HIPCHK(c, c->stage_fail_list.ensure((size_t)c->B));
+    HIPCHK(c, hipMemcpyAsync(c->stage_fail_count.p, c->fail_count.p, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->stage_fail_list.p, c->fail_list.p, (size_t)c->B * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+  }
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;
 }
@@ -928,7 +936,7 @@ int svnicp_get_knn_fallbacks(svnicp_ctx* c, int* out) {
   CTX_CHECK(c);
   if (!c->have_candidates) return fail(c, SVNICP_ERR_INVALID, "no candidates yet");
   if (c->knn_variant == 0) { *out = -1; return SVNICP_OK; }
-  return fetch(c, out, c->fail_count.p, sizeof(int));
+  return fetch(c, out, (c->tune.full_corr && c->stage_fail_count.p) ? c->stage_fail_count.p : c->fail_count.p, sizeof(int));
 }
 
 int svnicp_get_knn_fallback_rows(svnicp_ctx* c, int32_t* out, int cap, int* n_out) {
@@ -936,12 +944,13 @@ int svnicp_get_knn_fallback_rows(svnicp_ctx* c, int32_t* out, int cap, int* n_ou
   if (!c->have_candidates || !n_out) return fail(c, SVNICP_ERR_INVALID, "no candidates yet");
   *n_out = 0;
   if (c->knn_variant == 0) return SVNICP_OK;
+  const bool snap = c->tune.full_corr && c->stage_fail_count.p;
   int n = 0;
-  int rc = fetch(c, &n, c->fail_count.p, sizeof(int));
+  int rc = fetch(c, &n, snap ? c->stage_fail_count.p : c->fail_count.p, sizeof(int));
   if (rc) return rc;
   *n_out = n;
   if (n > cap) n = cap;
-  if (n > 0 && out) return fetch(c, out, c->fail_list.p, (size_t)n * 4);
+  if (n > 0 && out) return fetch(c, out, snap ? c->stage_fail_list.p : c->fail_list.p, (size_t)n * 4);
   return SVNICP_OK;
 }
 

@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256) void k_prep_crop(const float* __restrict__ in,
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double n2 = -1.0;
   if (i < n) {
-    const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
-    n2 = x * x + y * y + z * z;                       // registration_pipeline.hpp: crop_pointcloud, same order
+    const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+    n2 = (double)((x * x + y * y) + z * z);           // float32, left to right, as pt.x*pt.x + pt.y*pt.y + pt.z*pt.z of
+                                                      // OdometryPipeline.cpp:698 (this library is built with -ffp-contract=off)
     keep[i] = (n2 < max2 && n2 > min2) ? 1 : 0;
     if (!(n2 == n2)) n2 = -1.0;                       // a NaN point is dropped and does not count for the range
   }
@@ -328,6 +329,7 @@ int svnicp_prep_scan(svnicp_prep* p, const float* xyz, int64_t n, int mem_kind, 
 const float* svnicp_prep_cropped_devptr(svnicp_prep* p) { return p ? p->cropped.p : nullptr; }
 const float* svnicp_prep_map_cloud_devptr(svnicp_prep* p) { return p ? p->map_cloud.p : nullptr; }
 const double* svnicp_prep_source_devptr(svnicp_prep* p) { return p ? p->source64.p : nullptr; }
+const float* svnicp_prep_source_f32_devptr(svnicp_prep* p) { return p ? p->source.p : nullptr; }
 
 int svnicp_prep_download(svnicp_prep* p, int which, float* out_xyz, int64_t cap_points, int64_t* n_out) {
   if (!p || !n_out || which < 0 || which > 2) return SVNICP_ERR_INVALID;

@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned long long hash_key(unsigned long long k) {  
   return k;
 }
 
-struct MapPose { float R[9]; float t[3]; };
+struct MapPose { double R[9]; double t[3]; };
 
 // transform + voxel key + find-or-create the voxel's slot
 __global__ __launch_bounds__(256) void k_map_locate(const float* __restrict__ in, int64_t n, MapPose pose, float voxel,
@@ -54,9 +54,12 @@ __global__ __launch_bounds__(256) void k_map_locate(const float* __restrict__ in
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float p0 = in[3 * i], p1 = in[3 * i + 1], p2 = in[3 * i + 2];
+  // pcl::transformPointCloud with gtsam's double Matrix4 (VoxelHashMap.cpp:25): every coordinate is formed in double from the
+  // widened float32 point, left to right, and rounded ONCE to float32
   float c[3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) c[d] = (pose.R[3 * d] * p0 + pose.R[3 * d + 1] * p1 + pose.R[3 * d + 2] * p2) + pose.t[d];  // VoxelHashMap.cpp:25
+  for (int d = 0; d < 3; ++d)
+    c[d] = (float)(((pose.R[3 * d] * (double)p0 + pose.R[3 * d + 1] * (double)p1) + pose.R[3 * d + 2] * (double)p2) + pose.t[d]);
   q[3 * i] = c[0]; q[3 * i + 1] = c[1]; q[3 * i + 2] = c[2];
   long long v[3];
   bool ok = true;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void k_map_locate(const float* __restrict__ in
     ok = ok && (f >= (float)-kOff) && (f < (float)kOff);   // also false for NaN
     v[d] = ok ? (long long)f : 0;
   }
-  if (!ok) { slot_of[i] = 0xffffffffu; atomicOr(&stats[2], 1); return; }   // outside the index range: reported, not stored
+  if (!ok) { slot_of[i] = 0xffffffffu; atomicAdd(&stats[3], 1); return; }   // outside the index range or NaN: counted, not stored
   const unsigned long long key = ((unsigned long long)(v[0] + kOff) << 42) | ((unsigned long long)(v[1] + kOff) << 21) |
                                  (unsigned long long)(v[2] + kOff);
   unsigned long long h = hash_key(key) & (unsigned long long)(cap - 1);
@@ -269,6 +272,7 @@ struct svnicp_map {
   Buf<double> out;
   Buf<unsigned char> tmp;
   int64_t last_M = 0;
+  int64_t skipped = 0;   // points svnicp_map_add_cloud did not store (outside the index range or NaN), since creation / clear
   int h_stats[4] = {0, 0, 0, 0};
   std::string err;
 };
@@ -301,7 +305,7 @@ int read_stats(svnicp_map* m) {
 int rebuild(svnicp_map* m, int64_t new_cap) {
   Buf<unsigned long long> nk; Buf<int> nc; Buf<float> np;
   int rc = alloc_table(m, new_cap, nk, nc, np);
-  if (rc) return rc;
+  if (rc) { nk.release(); nc.release(); np.release(); return rc; }
   hipLaunchKernelGGL(k_map_rehash, dim3((unsigned)((m->cap + 255) / 256)), dim3(256), 0, m->stream, m->keys.p, m->counts.p, m->pts.p,
                      m->cap, m->max_points, nk.p, nc.p, np.p, new_cap, m->stats.p);
   MCHK(m, hipGetLastError());
@@ -362,6 +366,13 @@ int svnicp_map_clear(svnicp_map* m) {
   MCHK(m, hipMemsetAsync(m->stats.p, 0, 16, m->stream));
   MCHK(m, hipStreamSynchronize(m->stream));
   std::memset(m->h_stats, 0, sizeof m->h_stats);
+  m->skipped = 0;
+  return SVNICP_OK;
+}
+
+int svnicp_map_skipped_points(svnicp_map* m, int64_t* out) {
+  if (!m || !out) return SVNICP_ERR_INVALID;
+  *out = m->skipped;
   return SVNICP_OK;
 }
 
@@ -393,8 +404,8 @@ int svnicp_map_add_cloud(svnicp_map* m, const float* xyz, int64_t n, int mem_kin
     MCHK(m, m->q.ensure((size_t)n * 3)); MCHK(m, m->slot.ensure((size_t)n)); MCHK(m, m->sslot.ensure((size_t)n));
     MCHK(m, m->sidx_in.ensure((size_t)n)); MCHK(m, m->sidx.ensure((size_t)n));
     MapPose ps;
-    for (int i = 0; i < 9; ++i) ps.R[i] = (float)R_rowmajor[i];
-    for (int i = 0; i < 3; ++i) ps.t[i] = (float)t[i];
+    for (int i = 0; i < 9; ++i) ps.R[i] = R_rowmajor[i];
+    for (int i = 0; i < 3; ++i) ps.t[i] = t[i];
     const unsigned g = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_map_locate, dim3(g), dim3(256), 0, m->stream, din, n, ps, (float)m->voxel, m->keys.p, m->cap, m->q.p, m->slot.p, m->stats.p);
     MCHK(m, hipGetLastError());
@@ -416,12 +427,14 @@ int svnicp_map_add_cloud(svnicp_map* m, const float* xyz, int64_t n, int mem_kin
   MCHK(m, hipGetLastError());
   const int rc = read_stats(m);
   if (rc) return rc;
-  if (m->h_stats[2]) {
-    const int flags = m->h_stats[2], zero = 0;
-    MCHK(m, hipMemcpyAsync(m->stats.p + 2, &zero, sizeof(int), hipMemcpyHostToDevice, m->stream));
+  if (m->h_stats[2] || m->h_stats[3]) {
+    const int flags = m->h_stats[2], zero2[2] = {0, 0};
+    m->skipped += m->h_stats[3];    // points outside +-2^20 voxels or NaN: not stored, not an error — the map and its
+                                    // counters are consistent, the caller's drive goes on (svnicp_map_skipped_points)
+    MCHK(m, hipMemcpyAsync(m->stats.p + 2, zero2, sizeof zero2, hipMemcpyHostToDevice, m->stream));
     MCHK(m, hipStreamSynchronize(m->stream));
+    // cannot happen: the table is grown to twice the voxels this cloud could add before anything is inserted
     if (flags & 2) return mfail(m, SVNICP_ERR_NOMEM, "svnicp_map_add_cloud: hash table full");
-    return mfail(m, SVNICP_ERR_INVALID, "svnicp_map_add_cloud: a point lies outside +-2^20 voxels (or is NaN); it was not stored");
   }
   return SVNICP_OK;
 }

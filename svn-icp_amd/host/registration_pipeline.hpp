@@ -121,7 +121,11 @@ inline Cloud crop_pointcloud(const Cloud& in, double min_range, double max_range
   Cloud out;
   out.reserve(in.size());
   for (const auto& p : in) {
-    const double n2 = (double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2];
+    // float32, left to right, as pt.x * pt.x + pt.y * pt.y + pt.z * pt.z on pcl::PointXYZ (:698); volatile keeps a host
+    // compiler from contracting the sums into fused multiply-adds
+    volatile float xx = p[0] * p[0], yy = p[1] * p[1], zz = p[2] * p[2];
+    volatile float xy = xx + yy;
+    const double n2 = (double)(float)(xy + zz);
     if (n2 > *scan_max_range) *scan_max_range = n2;
     if (n2 < max_range * max_range && n2 > min_range * min_range) out.push_back(p);
   }
@@ -177,13 +181,13 @@ class VoxelHashMap {
   void Clear() { map_.clear(); }
 
   void AddPointCloud(const Cloud& cloud, const Pose3& pose) {
-    float Rf[9], tf[3];
-    for (int i = 0; i < 9; ++i) Rf[i] = (float)pose.R[i];
-    for (int i = 0; i < 3; ++i) tf[i] = (float)pose.t[i];
+    // pcl::transformPointCloud with gtsam's double Matrix4 (VoxelHashMap.cpp:23-25): formed in double from the widened float32
+    // point, left to right, rounded once to float32 (the expression of voxel_map.hip and pipeline.py)
     const float vs = (float)voxel_size_;
     for (const auto& p : cloud) {
       std::array<float, 3> q;
-      for (int i = 0; i < 3; ++i) q[i] = (Rf[3 * i] * p[0] + Rf[3 * i + 1] * p[1] + Rf[3 * i + 2] * p[2]) + tf[i];
+      for (int i = 0; i < 3; ++i)
+        q[i] = (float)(((pose.R[3 * i] * (double)p[0] + pose.R[3 * i + 1] * (double)p[1]) + pose.R[3 * i + 2] * (double)p[2]) + pose.t[i]);
       const Key k{(int64_t)std::trunc(q[0] / vs), (int64_t)std::trunc(q[1] / vs), (int64_t)std::trunc(q[2] / vs)};
       auto& v = map_[k];
       if ((int)v.size() < max_points_) v.push_back(q);
@@ -269,6 +273,7 @@ class DevicePrep {
   const float* cropped() { return svnicp_prep_cropped_devptr(p_); }
   const float* map_cloud() { return svnicp_prep_map_cloud_devptr(p_); }
   const double* source() { return svnicp_prep_source_devptr(p_); }
+  const float* source_f32() { return svnicp_prep_source_f32_devptr(p_); }
   std::vector<double> download_source() {   // test tap
     std::vector<float> f((size_t)3 * n_source);
     int64_t n = 0;
@@ -361,9 +366,11 @@ class RegistrationPipeline {
     std::vector<double> init = sample_particles();                                                     // :573
     res.initial_guess = guess;
     if (dmap_ ? dmap_->Empty() : map_.Empty()) {                                                       // :585-593
-      if (dprep_) dmap_->AddPointCloudDevice(dprep_->cropped(), dprep_->n_cropped, guess);
-      else if (dmap_) { dmap_->AddPointCloud(cropped, guess); bytes_h2d_ += cropped.size() * 12; }
-      else map_.AddPointCloud(cropped, guess);
+      // the reference's downsample_uniform filters its input IN PLACE (:684-690): at :585 *cropped_cloud already holds the
+      // 0.5-voxel sampling, and that is what seeds the map
+      if (dprep_) dmap_->AddPointCloudDevice(dprep_->map_cloud(), dprep_->n_map, guess);
+      else if (dmap_) { dmap_->AddPointCloud(to_map, guess); bytes_h2d_ += to_map.size() * 12; }
+      else map_.AddPointCloud(to_map, guess);
       poses_.push_back(guess); times_.push_back(stamp);
       res.pose = guess;
       return res;
@@ -401,9 +408,11 @@ class RegistrationPipeline {
     res.particles = solver_->get_particles();
     res.weights = solver_->get_particle_weight();
     res.pose = guess * correction_to_pose(res.correction);                                             // updater_, :37-46
-    if (dprep_) dmap_->AddPointCloudDevice(dprep_->map_cloud(), dprep_->n_map, res.pose);              // :630
-    else if (dmap_) { dmap_->AddPointCloud(to_map, res.pose); bytes_h2d_ += to_map.size() * 12; }
-    else map_.AddPointCloud(to_map, res.pose);
+    // … and at :630 *voxelized_cloud_toMap holds the 1.5-voxel sampling (the second in-place filter, :560): the map is updated
+    // with the same points the solver registered
+    if (dprep_) dmap_->AddPointCloudDevice(dprep_->source_f32(), dprep_->n_source, res.pose);          // :630
+    else if (dmap_) { dmap_->AddPointCloud(source, res.pose); bytes_h2d_ += source.size() * 12; }
+    else map_.AddPointCloud(source, res.pose);
     poses_.push_back(res.pose); times_.push_back(stamp);
     return res;
   }

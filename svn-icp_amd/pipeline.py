@@ -95,10 +95,13 @@ def crop_pointcloud(points: np.ndarray, min_range: float, max_range: float, scan
     Also returns the updated ``scan_max_range_`` — which the reference sets to the largest SQUARED norm seen
     (:699) and later uses as a length (:578); mirrored as is."""
     p = np.asarray(points, float)[:, :3]
-    n2 = (p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) + p[:, 2] * p[:, 2]     # the order of the C++ and device versions
+    f = p.astype(np.float32)
+    # float32 arithmetic, left to right, as pt.x*pt.x + pt.y*pt.y + pt.z*pt.z on pcl::PointXYZ (:698); the comparisons
+    # promote the float to double (max_range_ is a double)
+    n2 = ((f[:, 0] * f[:, 0] + f[:, 1] * f[:, 1]) + f[:, 2] * f[:, 2]).astype(np.float64)
     keep = (n2 < max_range * max_range) & (n2 > min_range * min_range)
-    if n2.size:
-        scan_max_range = max(scan_max_range, float(n2.max()))
+    if n2.size and not np.all(np.isnan(n2)):
+        scan_max_range = max(scan_max_range, float(np.nanmax(n2)))
     return p[keep], scan_max_range
 
 
@@ -126,14 +129,16 @@ def downsample_uniform(points: np.ndarray, radius: float) -> np.ndarray:
 
 # ----------------------------------------------------------------------------- local map
 def transform_f32(cloud, T) -> np.ndarray:
-    """pcl::transformPointCloud on float32 points: q = ((R0·x + R1·y) + R2·z) + t per component, every step rounded to
-    float32 — the same order as registration_pipeline.hpp and voxel_map.hip, so all three maps hold identical points."""
-    c = np.asarray(cloud, np.float32)
-    R = np.asarray(T, float)[:3, :3].astype(np.float32)
-    t = np.asarray(T, float)[:3, 3].astype(np.float32)
+    """pcl::transformPointCloud of float32 points with gtsam's DOUBLE Matrix4 (VoxelHashMap.cpp:23-25): every coordinate
+    q = ((R0·x + R1·y) + R2·z) + t is formed in float64 from the widened float32 point and rounded once to float32 — the
+    same expression as registration_pipeline.hpp and voxel_map.hip, so all three maps hold identical points.  (Parity with
+    PCL itself is unpinned: PCL is not in this image.)"""
+    c = np.asarray(cloud, np.float32).astype(np.float64)
+    R = np.asarray(T, float)[:3, :3]
+    t = np.asarray(T, float)[:3, 3]
     out = np.empty((c.shape[0], 3), np.float32)
     for d in range(3):
-        out[:, d] = ((R[d, 0] * c[:, 0] + R[d, 1] * c[:, 1]) + R[d, 2] * c[:, 2]) + t[d]
+        out[:, d] = (((R[d, 0] * c[:, 0] + R[d, 1] * c[:, 1]) + R[d, 2] * c[:, 2]) + t[d]).astype(np.float32)
     return out
 
 
@@ -177,6 +182,12 @@ class DeviceVoxelHashMap:
 
     def empty(self) -> bool:
         return len(self) == 0
+
+    def skipped_points(self) -> int:
+        """Points add_pointcloud has not stored (outside +-2^20 voxels, or NaN) since creation."""
+        n = self._C.c_int64(0)
+        self._chk(self._L.svnicp_map_skipped_points(self._h, self._C.byref(n)), "svnicp_map_skipped_points")
+        return int(n.value)
 
     def add_pointcloud(self, cloud: np.ndarray, pose: np.ndarray):
         C = self._C
@@ -272,6 +283,10 @@ class DevicePreprocessor:
     @property
     def map_cloud_ptr(self) -> int:
         return int(self._L.svnicp_prep_map_cloud_devptr(self._h) or 0)
+
+    @property
+    def source_f32_ptr(self) -> int:
+        return int(self._L.svnicp_prep_source_f32_devptr(self._h) or 0)
 
     @property
     def source_ptr(self) -> int:
@@ -432,10 +447,12 @@ class RegistrationPipeline:
         guess = pose_prediction(self.poses, self.times, stamp)                                                  # :563-564
         init = self._particles()                                                                                # :573
         if self.map.empty():                                                                                    # :585-593
+            # the reference's downsample_uniform filters its input IN PLACE (:684-690): at :585 *cropped_cloud already holds
+            # the 0.5-voxel sampling, and that is what seeds the map
             if dev:
-                self.map.add_pointcloud_device(self._prep.cropped_ptr, self._prep.n_cropped, guess)
+                self.map.add_pointcloud_device(self._prep.map_cloud_ptr, self._prep.n_map, guess)
             else:
-                self.map.add_pointcloud(cropped, guess)
+                self.map.add_pointcloud(to_map, guess)
             self.poses.append(guess); self.times.append(stamp)
             return ScanResult(stamp, guess, guess, preprocessing_s=time.perf_counter() - t0)
         if self._solver is None:
@@ -465,12 +482,14 @@ class RegistrationPipeline:
         pose = guess @ correction_to_pose(corr)                                                                 # updater_, :37-46
         res = ScanResult(stamp, pose, guess, corr, s.get_distribution(), s.get_cov_matrix(), s.get_particles().reshape(-1),
                          s.get_particle_weight(), t1 - t0, 0.0, int(state))
+        # … and at :630 *voxelized_cloud_toMap holds the 1.5-voxel sampling (the second in-place filter, :560): the map is
+        # updated with the same points the solver registered
         if dev:
-            self.map.add_pointcloud_device(self._prep.map_cloud_ptr, self._prep.n_map, pose)                    # :627
+            self.map.add_pointcloud_device(self._prep.source_f32_ptr, self._prep.n_source, pose)                # :630
         else:
-            self.map.add_pointcloud(to_map, pose)                                                               # :627
+            self.map.add_pointcloud(source, pose)                                                               # :630
             if c.gpu_map:
-                self.bytes_h2d += to_map.shape[0] * 12
+                self.bytes_h2d += source.shape[0] * 12
         self.poses.append(pose); self.times.append(stamp)                                                       # :630
         res.align_s = time.perf_counter() - t1
         return res

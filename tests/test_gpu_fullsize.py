@@ -129,3 +129,28 @@ def test_svgd_mode_at_production_particle_counts(hip, orc, P, B, M, opt, es):
     for got, want in ((s.get_transformation(), o.get_transformation()), (s.get_distribution(), o.get_distribution()),
                       (s.get_cov_matrix(), o.get_cov_matrix()), (s.get_particles(), o.get_particles())):
         assert np.allclose(got, want, rtol=0, atol=TIGHT)
+
+
+def test_svgd_adam_at_c3_size(hip, orc):
+    """SVGD-ICP (Adam, lr 0.01 — the configuration `bench.py --mode svgd` times) at C3's particle count, target cloud, K and
+    iteration count on 8192 evenly spaced source rows against the oracle: candidate lists bit-exact, every iteration's
+    correspondences bit-exact, gradients and Stein directions per iteration, final particles / mean / covariance to 1e-9."""
+    cfg = hip.scans.CONFIGS["C3"]
+    pair = hip.scans.make_pair(cfg["B"], cfg["M"])
+    rows = np.linspace(0, cfg["B"] - 1, 8192).astype(np.int64)
+    src = np.ascontiguousarray(pair.source[rows])
+    init = hip.scans.make_particles(cfg["P"])
+    c = dict(iterations=20, lr=0.01, max_dist=1.0, check_early_stop=False, convergence_threshold=1e-5, knn_count=100, optimizer="Adam")
+    o = orc.Solver(init, mode=orc.MODE_SVGD, svn_full_grad=False, **c)
+    o.add_cloud(src, pair.target, init); tro = o.enable_trace(); o.stein_align()
+    s = _hip_svgd(hip, init, c); s.add_cloud(src, pair.target, init); s.set_initial_mean(np.eye(4))
+    assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+    assert np.array_equal(s.get_candidates().astype(np.int64), o.candidates())
+    tr = s.get_trace()
+    assert np.array_equal(tr["corr"], tro["corr"])
+    assert np.allclose(tr["newton"], tro["newton"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(tr["phi"], tro["phi"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(tr["h"], tro["h"], rtol=1e-10)
+    for got, want in ((s.get_transformation(), o.get_transformation()), (s.get_cov_matrix(), o.get_cov_matrix()),
+                      (s.get_particles(), o.get_particles())):
+        assert np.allclose(got, want, rtol=0, atol=TIGHT)

@@ -894,13 +894,14 @@ def test_c2_full_parity(hip, orc):
     assert err[:3].max() < POSE_TOL and err[3:].max() < POSE_TOL
 
 
-@pytest.mark.parametrize("wl,Bs,iters", [("C3", 4096, 20), ("C4", 1536, 8), ("C5", 2048, 6)])
+@pytest.mark.parametrize("wl,Bs,iters", [("C3", 4096, 20), ("C4", 16384, 20), ("C5", 4096, 20)])
 def test_headline_configs_reduced_source_full_parity(hip, orc, wl, Bs, iters):
     """BASELINE configs C3 / C4 / C5 with their real particle count, K, target cloud and (for C3) iteration
     count, on an evenly spaced subset of the source scan so that the CPU oracle finishes in seconds: candidate
     lists and dist² bit-exact, per-iteration correspondences bit-exact, H/b/step to the trace tolerances, pose,
-    covariance and particles to 1e-9.  C4 exercises the workgroup-parallel Stein update (512 particles), C5 the
-    2 M-point target (4096 Morton tiles, sliced fallback)."""
+    covariance and particles to 1e-9.  All three run their full 20 iterations.  C4 (16384 rows) exercises the pair statistics
+    of 512 particles (k_upd_hist chain) and four particle groups per search wave, C5 (4096 rows) the 2 M-point target
+    (4096 Morton tiles, sliced fallback)."""
     cfg = hip.scans.CONFIGS[wl]
     pair = hip.scans.make_pair(cfg["B"], cfg["M"])
     rows = np.linspace(0, cfg["B"] - 1, Bs).astype(np.int64)

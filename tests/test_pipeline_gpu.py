@@ -38,7 +38,10 @@ def test_registration_pipeline_tracks_a_synthetic_drive(hip):
     eyaw = np.array([np.linalg.norm(pl.so3_log(T[:3, :3].T @ E[:3, :3])) for T, E in zip(truth, est)])
     print("z error of prediction / estimate per frame:", np.round(ez_guess, 3), np.round(ez, 3), "rot err", np.round(eyaw, 4))
     assert ez[1] < 0.5 * ez_guess[1]                      # first registration: the prediction is a full step off
-    assert ez.max() < 0.03 and est[-1][2, 3] > 0.9 * truth[-1][2, 3]
+    # (the map follows the reference's data flow: seeded with the 0.5-voxel sampling, updated with the 1.5-voxel one — the
+    # source points themselves, OdometryPipeline.cpp:559-560,585,630 — so it is sparse: 0.035 m here, 0.02 m with a map
+    # fed the 0.5-voxel cloud every frame as rounds 1-2 did)
+    assert ez.max() < 0.05 and est[-1][2, 3] > 0.9 * truth[-1][2, 3]
     assert eyaw[-1] < 0.01
     assert len(pipe.map) > 1000
 

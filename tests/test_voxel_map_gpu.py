@@ -67,10 +67,14 @@ def test_device_map_grows_and_rejects_out_of_range(hip):
     assert len(dm) == len(hm) > 100000
     dm.get_map()
     assert np.array_equal(dm.download(), _host_rows(hm))
-    far = np.array([[1e9, 0, 0]], np.float32)            # voxel index beyond +-2^20: refused loudly, nothing stored
-    with pytest.raises(hip.SvnIcpError):
-        dm.add_pointcloud(far, np.eye(4))
+    # voxel index beyond +-2^20 or NaN: the point is counted and not stored, the call succeeds (one stray point of a scan
+    # must not abort a drive whose map has already been updated) and the rest of the cloud goes in
+    mixed = np.array([[1e9, 0, 0], [40.5, 40.5, 40.5], [np.nan, 0, 0]], np.float32)
+    dm.add_pointcloud(mixed, np.eye(4)); hm.add_pointcloud(mixed[1:2], np.eye(4))
+    assert dm.skipped_points() == 2
     assert len(dm) == len(hm)
+    dm.get_map()
+    assert np.array_equal(dm.download(), _host_rows(hm))
 
 
 def test_pipeline_with_device_map_matches_host_map(hip):

@@ -129,6 +129,7 @@ int svnicp_get_runtime(svnicp_ctx *ctx, double out3[3]);             /* SVGDICP.
 /* test / profiling knobs of a context, by name (the product configuration is the default of every one):
  *   knn = auto|v1|v2        fallback_sliced_max = <n>      accum = split|mfma|valu|f64      search = bf16|f32
  *   update = auto|fused     fused_update_max_p = <P>       wgpcu = <search>,<accumulate>     tp = <points>    debug = 0|1
+ *   single = fused|split    correspondence = fast|full
  * The environment variable SVNICP_OPTIONS ("name=value;name=value") is read once, in svnicp_create. */
 int svnicp_set_option(svnicp_ctx *ctx, const char *name, const char *value);
 

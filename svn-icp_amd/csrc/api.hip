@@ -47,6 +47,7 @@ struct svnicp_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool median_pending = false;
+  int single_done_it = -1;   // iteration whose Stein step the accumulate kernel's last workgroup has already enqueued (P = 1)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   std::string err;
 
@@ -391,6 +392,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "scan_split") ok = num(0, 16, &t.scan_split);
   else if (k == "group_stride") ok = num(0, 1 << 30, &t.group_stride);
   else if (k == "accum_min_steps") ok = num(0, 1 << 20, &t.accum_min_steps);
+  else if (k == "single") { if (v == "fused") t.single_fused = 1; else if (v == "split") t.single_fused = 0; else ok = false; }
   else if (k == "correspondence") { if (v == "fast") t.full_corr = 0; else if (v == "full") t.full_corr = 1; else ok = false; }
   else return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: unknown option '" + k + "'");
   if (!ok) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: bad value '" + v + "' for option '" + k + "'");
@@ -541,6 +543,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->trh.p, 0, ((size_t)I + 1) * 8, c->stream));
   }
   c->pused = 0;
+  c->single_done_it = -1;
   if (c->median_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // a registration that was abandoned between its two per-iteration calls
   c->median_pending = false;
   HIPCHK(c, hipMemsetAsync(c->uctl.p, 0, update_uctl_doubles(P) * sizeof(double), c->stream));   // tickets, counters, pair histogram
@@ -770,9 +773,16 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
     HIPCHK(c, launch_search_split(c->plan, a, c->stream));
     HIPCHK(c, prof_end(c));
   }
+  // ONE particle, no exchange between ranks ahead, the fused f32 kernel: its last workgroup reduces the partial sums and
+  // runs the Stein step (for P = 1 the Newton step and the pose update) — the iteration is this one launch
+  const bool single = c->P == 1 && c->prm.mode == SVNICP_MODE_SVN && c->row_world == 1 && c->p_lo == 0 && c->p_hi == 1 &&
+                      !c->tune.full_corr && c->tune.single_fused && accumulate_can_fuse_single(c->plan);
+  const UpdateArgs us = update_args(c, it);
+  a.ticket = reinterpret_cast<unsigned int*>(c->uctl.p + 41);
   HIPCHK(c, prof_begin(c, KC_ACCUM));
-  HIPCHK(c, launch_accumulate(c->plan, a, c->stream));
+  HIPCHK(c, launch_accumulate(c->plan, a, single ? &us : nullptr, c->stream));
   HIPCHK(c, prof_end(c));
+  if (single) { c->single_done_it = it; return SVNICP_OK; }
   HIPCHK(c, prof_begin(c, KC_REDUCE));
   // one rank: the particle's record; source-row sharding: this rank's slot of the [row_world][P][22] array
   double* rec = c->row_world > 1 ? c->rank_sums.p + (size_t)c->row_rank * c->P * kNSums : c->sums.p;
@@ -786,6 +796,7 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
   if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_update: call svnicp_align_begin first");
   if (it < 0 || it >= c->prm.iterations) return fail(c, SVNICP_ERR_INVALID, "svnicp_iter_update: bad iteration");
   if (bind(c)) return SVNICP_ERR_HIP;
+  if (c->single_done_it == it) { c->single_done_it = -1; return SVNICP_OK; }   // done by the accumulate kernel's last workgroup
   if (c->tune.debug && !c->dbg_upd) { HIPCHK(c, hipMalloc(&c->dbg_upd, 8 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->dbg_upd, 0, 8 * sizeof(unsigned long long))); }
   UpdateArgs u = update_args(c, it);
   HIPCHK(c, prof_begin(c, KC_UPDATE));

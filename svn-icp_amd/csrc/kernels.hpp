@@ -133,6 +133,7 @@ struct AccumArgs {
   uint8_t* kbest;       // split variant: winner index per (source point, particle of the shard), [B][Ppad]
   const int32_t* full_idx;  // correspondence = full: nearest target index of every (particle, source point), [P][B]; else nullptr
   int pts_per_block, spts_per_block;  // split variant: source points per workgroup (accumulate / search kernel)
+  unsigned int* ticket;               // fused one-particle iteration: arrival counter of the accumulate kernel's workgroups
 };
 struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem;
                    int search_f32; /* split variant: 1 = f32-input MFMA search kernel (A/B), 0 = bf16x3 matrix pipe (default) */ };
@@ -152,6 +153,7 @@ struct Tuning {
   int group_stride = 0;          // stage A scan: group order stride (0 = default, 1 = natural order)
   int scan_split = 0;            // stage A scan: waves per 64-query workgroup, 4 or 8 (0 = default)
   int debug = 0;                 // print plans and per-phase cycle counters to stderr
+  int single_fused = 1;          // one particle: reduce + Stein step in the accumulate kernel's last workgroup (0: three launches, A/B)
   int full_corr = 0;             // 1: correspondence = full — per-particle exact NN over the whole target (SVGDICP.cpp:274-298)
 };
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune);
@@ -165,7 +167,6 @@ hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const doubl
                                double* anchor, float4* tablea, float4* tail, float* cmax, hipStream_t st);
 hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
                                float4* tablef, float* cmax, hipStream_t st);
-hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st);
 // q[b] = (s·R^T) + t with the stage-B expression (SVNICP.cpp:62-64); pose12 = device [R row-major | t]
 hipError_t launch_transform_cloud(const double* src, int64_t B, const double* pose12, double* q, const int* ctl, hipStream_t st);
 // ---------------- particle update (particle_update.hip) ----------------
@@ -197,6 +198,9 @@ struct UpdateArgs {
 size_t update_workspace_doubles(int P);
 hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose, int mode, double* R, double* t,
                                  double* Rtot, double* pose_out, int refresh_pose, double* eul, hipStream_t st);
+// stage B accumulate (fused variants: whole stage B); single: see stein_iter.hip — the one-particle iteration in one launch
+bool accumulate_can_fuse_single(const AccumPlan& plan);
+hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, const UpdateArgs* single, hipStream_t st);
 hipError_t launch_update_svgd(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
 // the Stein step of P >= 2 particles in three pieces (particle_update.hip): pair statistics (second stream), sums -> H, b,

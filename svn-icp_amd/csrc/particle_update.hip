@@ -8,6 +8,7 @@
 // In the multi-GPU layout every GPU runs this kernel redundantly on ALL particles after the
 // all-gather of the 22 raw sums per particle; identical inputs + identical code ⇒ identical state.
 #include "kernels.hpp"
+#include "update_single.hpp"
 
 namespace svnicp {
 
@@ -26,40 +27,6 @@ struct Work {
     sq = phi + (size_t)P * 6;
   }
 };
-
-// H (6x6) and b (6) of one particle from its 22 raw sums and Rc = R0·R  (see stein_iter.hip)
-__device__ void finalize_Hb(const double* s, const double* Rc, double* H, double* b) {
-  const double sw = s[0];
-  const double a0 = s[1], a1 = s[2], a2 = s[3];
-  const double xx = s[4], xy = s[5], xz = s[6], yy = s[7], yz = s[8], zz = s[9];
-  const double tr = xx + yy + zz;
-#pragma unroll
-  for (int i = 0; i < 36; ++i) H[i] = 0.0;
-  H[0] = H[7] = H[14] = sw;                      // Σ w·I
-  // top-right −Σw·ŝ, bottom-left +Σw·ŝ with ŝ = [[0,−s2,s1],[s2,0,−s0],[−s1,s0,0]]
-  H[0 * 6 + 4] = a2;  H[0 * 6 + 5] = -a1;
-  H[1 * 6 + 3] = -a2; H[1 * 6 + 5] = a0;
-  H[2 * 6 + 3] = a1;  H[2 * 6 + 4] = -a0;
-  H[3 * 6 + 1] = -a2; H[3 * 6 + 2] = a1;
-  H[4 * 6 + 0] = a2;  H[4 * 6 + 2] = -a0;
-  H[5 * 6 + 0] = -a1; H[5 * 6 + 1] = a0;
-  // bottom-right Σw(‖s‖²I − ssᵀ)
-  H[3 * 6 + 3] = tr - xx; H[3 * 6 + 4] = -xy;     H[3 * 6 + 5] = -xz;
-  H[4 * 6 + 3] = -xy;     H[4 * 6 + 4] = tr - yy; H[4 * 6 + 5] = -yz;
-  H[5 * 6 + 3] = -xz;     H[5 * 6 + 4] = -yz;     H[5 * 6 + 5] = tr - zz;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) H[7 * i] += 1e-6;  // SVNICP.cpp:153
-  // b_t = Rcᵀ Σwe ; b_r = vee-part of G = Rcᵀ·C, C[i][j] = Σ (we)_i s_j
-  mat3T_vec(Rc, s + 10, b);
-  double G[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) G[3 * i + j] = Rc[i] * s[13 + j] + Rc[3 + i] * s[16 + j] + Rc[6 + i] * s[19 + j];
-  b[3] = G[7] - G[5];  // s_y u_z − s_z u_y  with u_i s_j = G[i][j]
-  b[4] = G[2] - G[6];
-  b[5] = G[3] - G[1];
-}
 
 // The 22 raw sums of particle p.  One rank (or particle sharding): the context's own record.  Source-row sharding
 // (svnicp_set_row_shard): a.sums is the all-gathered [n_ranks][P][22] array of the ranks' partial records — rank r summed

@@ -31,13 +31,56 @@
 
 #include "kernels.hpp"
 #include "stein_common.hpp"
+#include "update_single.hpp"
 
 namespace svnicp {
 
 namespace {
 
+// ONE particle and nothing between the sums and the update (no exchange between ranks): the workgroup that finishes last —
+// one __threadfence and one atomic ticket per workgroup, nobody waits — adds the workgroups' partial sums in block order
+// and runs the whole Stein step (update_single.hpp: for P = 1 it is the Newton step and the pose update, a few
+// microseconds on one thread).  An iteration of a plain-ICP registration is then ONE launch instead of three
+// (accumulate, k_reduce_partials, k_particle_update).  Block-wide call; `lds` = the kernel's dynamic LDS (free by now).
+__device__ inline void single_particle_tail(const AccumArgs& a, const UpdateArgs& u, double* lds) {
+  __shared__ int sh_last;
+  const int tid = threadIdx.x;
+  __threadfence();                       // this workgroup's partial sums are device-visible before its ticket
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int t = atomicAdd(a.ticket, 1u);
+    sh_last = t == gridDim.x * gridDim.y - 1;
+    if (sh_last) *a.ticket = 0u;         // ready for the next iteration (stream order)
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  __threadfence();                       // the other workgroups' partial sums
+  constexpr int RL = 11;                 // 11 block lanes x 22 entries = 242 of the 256 threads
+  double (*red)[kNSums + 1] = reinterpret_cast<double (*)[kNSums + 1]>(lds);
+  const int es = tid % kNSums, bl = tid / kNSums;
+  const int nblk = (int)gridDim.x;
+  if (bl < RL) {
+    const size_t stride = (size_t)a.Ppad * kNSums;
+    const double* src = a.partial + es;  // particle lane 0 of the shard
+    double v = 0.0;
+    for (int blk = bl; blk < nblk; blk += RL) v += src[(size_t)blk * stride];
+    red[bl][es] = v;
+  }
+  __syncthreads();
+  double* sums = lds + RL * (kNSums + 1);
+  if (tid < kNSums) {
+    double v = red[0][tid];
+#pragma unroll
+    for (int k = 1; k < RL; ++k) v += red[k][tid];
+    sums[tid] = v;
+    const_cast<double*>(u.sums)[tid] = v;   // svnicp_sums_devptr stays meaningful
+  }
+  __syncthreads();
+  if (tid == 0) update_single_particle(u, sums);
+}
+
 template <int PW, int WP>
-__global__ __launch_bounds__(NT) void k_stein_accumulate(AccumArgs a) {
+__global__ __launch_bounds__(NT) void k_stein_accumulate(AccumArgs a, UpdateArgs u, int fuse_single) {
   if (a.ctl[0]) return;  // early stop already signalled (SVNICP.cpp:95-101)
   constexpr int BW = kWave / PW;  // source points per wave pass
   constexpr int WB = 4 / WP;      // waves along the source-point axis
@@ -184,7 +227,7 @@ __global__ __launch_bounds__(NT) void k_stein_accumulate(AccumArgs a) {
 // kernel, so correspondences and sums are bit-identical to it.
 // ---------------------------------------------------------------------------------------------
 template <int PW, int WP>
-__global__ __launch_bounds__(NT, 4) void k_stein_accumulate_f32(AccumArgs a) {
+__global__ __launch_bounds__(NT, 4) void k_stein_accumulate_f32(AccumArgs a, UpdateArgs u, int fuse_single) {
   if (a.ctl[0]) return;
   constexpr int BW = kWave / PW;
   constexpr int WB = 4 / WP;
@@ -347,6 +390,7 @@ __global__ __launch_bounds__(NT, 4) void k_stein_accumulate_f32(AccumArgs a) {
 #pragma unroll
     for (int i = 0; i < kNSums; ++i) out[i] = acc[i];
   }
+  if (fuse_single) single_particle_tail(a, u, lds);
 }
 
 // candidate table: f64 absolute coordinates (target_batch = index_select(target, sourceKNN_idx),
@@ -380,14 +424,16 @@ __global__ __launch_bounds__(256) void k_build_table2(const int32_t* __restrict_
 // (k_reduce_partials lives in particle_update.hip: its last workgroup goes on with the sums-dependent half of the Stein step)
 
 template <int PW, int WP>
-hipError_t launch_t(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
+hipError_t launch_t(const AccumPlan& plan, const AccumArgs& a, const UpdateArgs* single, hipStream_t st) {
   auto kern = plan.f32 ? k_stein_accumulate_f32<PW, WP> : k_stein_accumulate<PW, WP>;
   if (plan.smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a);
+  UpdateArgs u{};
+  if (single) u = *single;
+  hipLaunchKernelGGL(kern, dim3(plan.grid_x, plan.grid_y), dim3(NT), plan.smem, st, a, u, (single && plan.f32 == 1) ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -483,20 +529,23 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
   return pl;
 }
 
-hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, hipStream_t st) {
+// single != nullptr (one particle, fused f32 kernel, no exchange between ranks): the kernel's last workgroup also reduces
+// the partial sums and runs the Stein step — the caller launches neither k_reduce_partials nor an update kernel
+bool accumulate_can_fuse_single(const AccumPlan& plan) { return plan.f32 == 1 && plan.smem >= (size_t)(12 * (kNSums + 1)) * sizeof(double); }
+hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, const UpdateArgs* single, hipStream_t st) {
   a.TP = plan.TP; a.RS = plan.RS; a.tiles_per_block = plan.tiles_per_block; a.n_tiles = plan.n_tiles;
   a.Ppad = plan.Ppad;
   a.pts_per_block = plan.pts_per_block; a.spts_per_block = plan.spts_per_block;
   if (plan.f32 == 3) return launch_accumulate_split(plan, a, st);
   if (plan.f32 == 2) return launch_accumulate_mfma(plan, a, st);
   switch (plan.PW) {
-    case 8: return launch_t<8, 1>(plan, a, st);
-    case 16: return launch_t<16, 1>(plan, a, st);
-    case 32: return launch_t<32, 1>(plan, a, st);
+    case 8: return launch_t<8, 1>(plan, a, single, st);
+    case 16: return launch_t<16, 1>(plan, a, single, st);
+    case 32: return launch_t<32, 1>(plan, a, single, st);
     default:
-      if (plan.WP == 1) return launch_t<64, 1>(plan, a, st);
-      if (plan.WP == 2) return launch_t<64, 2>(plan, a, st);
-      return launch_t<64, 4>(plan, a, st);
+      if (plan.WP == 1) return launch_t<64, 1>(plan, a, single, st);
+      if (plan.WP == 2) return launch_t<64, 2>(plan, a, single, st);
+      return launch_t<64, 4>(plan, a, single, st);
   }
 }
 

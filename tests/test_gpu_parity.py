@@ -503,6 +503,29 @@ def test_error_paths(hip):
         hip.SVNICP(hip.SteinICPParam(iterations=2, KNN_count=0), np.zeros((6, 2)))
 
 
+@pytest.mark.parametrize("es", [False, True])
+def test_single_particle_fused_iteration(hip, orc, es):
+    """One particle (plain ICP through the solver, BASELINE C1's shape): by default the accumulate kernel's last workgroup
+    reduces the partial sums and runs the Stein step, one launch per iteration; option single=split keeps the three
+    launches (accumulate, k_reduce_partials, k_particle_update).  Same correspondences, same iteration count, poses equal to
+    rounding (the two reductions group the workgroups' sums differently) and both equal to the oracle."""
+    B, M, K, I = 3000, 9000, 40, 25
+    src, tgt = hip.scans.random_clouds(B, M, seed=71, extent=20.0)
+    init = np.zeros((6, 1))
+    cfg = dict(iterations=I, lr=1.0, max_dist=1.0, check_early_stop=es, convergence_threshold=2e-3, knn_count=K, svn_full_grad=False)
+    o = orc.Solver(init, **cfg); o.add_cloud(src, tgt, init); tro = o.enable_trace(); o.stein_align()
+    out = {}
+    for mode in ("fused", "split"):
+        s = _hip_solver(hip, init, **cfg); s.set_option("single", mode); s.add_cloud(src, tgt, init)
+        assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+        _compare(s, o, tro, 1)
+        out[mode] = (s.get_particles(), s.get_trace()["corr"], s.get_iterations_run())
+    assert np.array_equal(out["fused"][1], out["split"][1]) and out["fused"][2] == out["split"][2] == o.iterations_run()
+    assert np.allclose(out["fused"][0], out["split"][0], rtol=0, atol=1e-12)
+    if es:
+        assert o.iterations_run() < I
+
+
 # ------------------------------------------------------------------ split-phase ABI (multi-GPU path) on one GPU
 def test_split_phase_two_shards_equal_single_context(hip):
     """Two contexts on one GPU play two ranks: particle shards [0,P/2) and [P/2,P), candidate rows

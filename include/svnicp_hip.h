@@ -127,7 +127,7 @@ int svnicp_get_particle_history(svnicp_ctx *ctx, float *outIx6P);    /* SVGDICP.
 int svnicp_get_runtime(svnicp_ctx *ctx, double out3[3]);             /* SVGDICP.h:94-96 {knn_s, update_s, finish_iter} */
 
 /* test / profiling knobs of a context, by name (the product configuration is the default of every one):
- *   knn = auto|v1|v2        fallback_sliced_max = <n>      accum = split|mfma|valu|f64      search = bf16|f32
+ *   knn = auto|v1|v2        fallback_sliced_max = <n>      accum = split|valu|f64
  *   update = auto|fused     fused_update_max_p = <P>       wgpcu = <search>,<accumulate>     tp = <points>    debug = 0|1
  *   single = fused|split    correspondence = fast|full
  * The environment variable SVNICP_OPTIONS ("name=value;name=value") is read once, in svnicp_create. */
@@ -223,7 +223,7 @@ int svnicp_get_ambiguous_pairs(svnicp_ctx *ctx, int64_t *out);
  * context's stream; svnicp_get_kernel_ms then returns the summed milliseconds and launch counts
  * per kernel class of the LAST align, SVNICP_KERNEL_CLASSES entries in this order:
  *   0 stage A (ordering + k_knn_tiles/k_knn_scan + fallback)   1 k_build_table*
- *   2 k_stein_search_mfma (split stage B only)                 3 k_stein_accumulate* (fused variants: whole stage B)
+ *   2 k_stein_search_bf16 (split stage B only)                 3 k_stein_accumulate* (fused variants: whole stage B)
  *   4 k_reduce_partials                                        5 k_particle_update / k_upd_* */
 #define SVNICP_KERNEL_CLASSES 6
 /* on: 0 = off, 1 = every class, otherwise a mask with bit (class + 1) set for each class to bracket (the event

@@ -77,7 +77,7 @@ struct svnicp_ctx {
   DevBuf<int32_t> sl_i;
   int sliced_max = 0;  // set at align_begin (kFallbackSlicedMax or SVNICP_FALLBACK_SLICED_MAX)
   DevBuf<int> ambig;
-  int accum_mode = 3;  // 0 f64 baseline, 1 f32 VALU search, 2 fused f32 MFMA search, 3 MFMA search + accumulate kernels
+  int accum_mode = 3;  // 0 f64 baseline, 1 f32 VALU search (fused), 3 bf16 matrix-pipe search + accumulate kernels
   DevBuf<unsigned long long> emax;
   DevBuf<int> fail_count;
   // correspondence = full reuses fail_list / fail_count for every per-particle search: stage A's own are kept here
@@ -382,8 +382,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   bool ok = true;
   if (k == "knn") { if (v == "auto") t.knn = -1; else if (v == "v1") t.knn = 0; else if (v == "v2") t.knn = 1; else ok = false; }
   else if (k == "fallback_sliced_max") ok = num(-1, 1 << 20, &t.fallback_sliced_max);
-  else if (k == "accum") { if (v == "f64") t.accum = 0; else if (v == "valu") t.accum = 1; else if (v == "mfma") t.accum = 2; else if (v == "split") t.accum = 3; else ok = false; }
-  else if (k == "search") { if (v == "bf16") t.search_f32 = 0; else if (v == "f32") t.search_f32 = 1; else ok = false; }
+  else if (k == "accum") { if (v == "f64") t.accum = 0; else if (v == "valu") t.accum = 1; else if (v == "split") t.accum = 3; else ok = false; }
   else if (k == "update") { if (v == "auto") t.update_fused = 0; else if (v == "fused") t.update_fused = 1; else ok = false; }
   else if (k == "fused_update_max_p") ok = num(1, 700, &t.fused_update_max_p);   // P = 1 has no pair statistics; the fused kernel's LDS ends near P = 800
   else if (k == "wgpcu") { int x = 0, y = 0; ok = sscanf(v.c_str(), "%d,%d", &x, &y) == 2 && x >= 0 && x <= 64 && y >= 0 && y <= 16; if (ok) { t.wgpcu_search = x; t.wgpcu_accum = y; } }
@@ -503,7 +502,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
   }
   HIPCHK(c, c->cand_idx.ensure((size_t)B * c->K));
   HIPCHK(c, c->cand_d2.ensure((size_t)B * c->K));
-  c->accum_mode = c->tune.accum;   // option "accum": f64 | valu | mfma | split
+  c->accum_mode = c->tune.accum;   // option "accum": f64 | valu | split
   HIPCHK(c, c->cmaxb.ensure((size_t)B));
   HIPCHK(c, c->ambig.ensure(2));   // [0] wave steps with an undecided lane, [1] undecided (point, particle) pairs
   HIPCHK(c, hipMemsetAsync(c->ambig.p, 0, 2 * sizeof(int), c->stream));
@@ -522,10 +521,10 @@ int svnicp_align_begin(svnicp_ctx* c) {
     HIPCHK(c, c->partial.ensure((size_t)c->plan.grid_x * c->plan.Ppad * kNSums));
   } else {
     c->plan = AccumPlan{};
-    c->plan.f32 = c->accum_mode >= 2 ? 1 : c->accum_mode;
+    c->plan.f32 = c->accum_mode == 3 ? 1 : c->accum_mode;
   }
   if (c->plan.f32 != 3) HIPCHK(c, c->table.ensure((size_t)B * c->K * 3));  // the split variant gathers from the target cloud
-  if (c->plan.f32 >= 2) { HIPCHK(c, c->tablea.ensure((size_t)B * 128)); HIPCHK(c, c->anchor.ensure((size_t)B * 3)); HIPCHK(c, c->tail.ensure((size_t)B * 4)); }
+  if (c->plan.f32 == 3) { HIPCHK(c, c->tablea.ensure((size_t)B * 128)); HIPCHK(c, c->anchor.ensure((size_t)B * 3)); HIPCHK(c, c->tail.ensure((size_t)B * 4)); }
   if (c->plan.f32 == 3) HIPCHK(c, c->kbest.ensure((size_t)B * c->plan.Ppad));
   else HIPCHK(c, c->tablef.ensure((size_t)B * c->K));
   if (c->prm.record_trace) {
@@ -689,7 +688,7 @@ int svnicp_build_candidate_table(svnicp_ctx* c) {
   if (!c->began) return fail(c, SVNICP_ERR_INVALID, "svnicp_build_candidate_table: call svnicp_align_begin first");
   if (bind(c)) return SVNICP_ERR_HIP;
   HIPCHK(c, prof_begin(c, KC_TABLE));
-  if (c->plan.f32 >= 2)
+  if (c->plan.f32 == 3)
     HIPCHK(c, launch_build_table3(c->cand_idx.p, c->B, c->K, c->tgt.p, c->M, c->plan.f32 == 3 ? nullptr : c->table.p,
                                   c->anchor.p, c->tablea.p, c->tail.p, c->cmaxb.p, c->stream));
   else
@@ -982,7 +981,7 @@ int svnicp_get_ambiguous_steps(svnicp_ctx* c, int* out) {
 int svnicp_get_ambiguous_pairs(svnicp_ctx* c, int64_t* out) {
   CTX_CHECK(c);
   if (!c->have_result || !out) return fail(c, SVNICP_ERR_INVALID, "no registration result yet");
-  if (c->accum_mode != 3 || c->plan.f32 != 3 || c->plan.search_f32) { *out = -1; return SVNICP_OK; }   // counted by the bf16 search kernel only
+  if (c->accum_mode != 3 || c->plan.f32 != 3) { *out = -1; return SVNICP_OK; }   // counted by the bf16 search kernel only
   int v[2] = {0, 0};
   const int rc = fetch(c, v, c->ambig.p, sizeof v);
   *out = v[1];

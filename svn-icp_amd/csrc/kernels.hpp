@@ -107,7 +107,7 @@ struct AccumArgs {
   const double* src;    // [B][3]
   const double* table;  // [B][K][3] candidate coordinates (f64, absolute)
   const float4* tablef; // [B][K] float32 local coordinates + |c'|² (fast variant)
-  const float4* tablea; // [B][2][64] float32 local rows in MFMA A-operand order (stein_mfma.hip)
+  const float4* tablea; // [B][2][64] float32 local rows in MFMA A-operand order (stein_split.hip: k_build_table3)
   const float* cmax;    // [B] max |c'| per source point (fast variants)
   int* ambig_count;     // optional statistic: wave steps that took the exact path, or nullptr
   const double* Rtot;   // [P][12]: R_total row-major (9) + t_total (3)
@@ -135,16 +135,14 @@ struct AccumArgs {
   int pts_per_block, spts_per_block;  // split variant: source points per workgroup (accumulate / search kernel)
   unsigned int* ticket;               // fused one-particle iteration: arrival counter of the accumulate kernel's workgroups
 };
-struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem;
-                   int search_f32; /* split variant: 1 = f32-input MFMA search kernel (A/B), 0 = bf16x3 matrix pipe (default) */ };
-// f32: 0 = float64 baseline, 1 = float32 VALU search, 2 = float32 MFMA search fused with the accumulation,
-// 3 = MFMA search kernel + accumulation kernel (2 and 3 fall back to 1 when K > 128 or P <= 8)
+struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem; };
+// f32: 0 = float64 baseline, 1 = float32 VALU search (fused with the accumulation), 3 = bf16 matrix-pipe search kernel +
+// accumulation kernel (falls back to 1 when K > 128 or the shard has <= 8 particles)
 // test / profiling knobs of a context (svnicp_set_option); the defaults are the product configuration
 struct Tuning {
   int knn = -1;                  // stage A kernel: -1 automatic, 0 streaming only (v1), 1 seeded scan (v2)
   int fallback_sliced_max = -1;  // stage A: failed queries redone by target slices up to this many (-1 default)
-  int accum = 3;                 // stage B: 0 f64 baseline, 1 f32 VALU search, 2 fused MFMA search, 3 search + accumulate kernels
-  int search_f32 = 0;            // split stage B: 1 = f32-input MFMA search kernel, 0 = bf16x3 matrix pipe
+  int accum = 3;                 // stage B: 0 f64 baseline, 1 f32 VALU search (fused), 3 search + accumulate kernels
   int update_fused = 0;          // Stein update: 1 = one fused kernel for 2 <= P <= fused_update_max_p
   int fused_update_max_p = 128;  // above this the Stein step runs as workgroup-parallel kernels
   int wgpcu_search = 0, wgpcu_accum = 0;   // workgroups per CU the stage-B grids are sized for (0 = automatic)
@@ -157,11 +155,9 @@ struct Tuning {
   int full_corr = 0;             // 1: correspondence = full — per-particle exact NN over the whole target (SVGDICP.cpp:274-298)
 };
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune);
-int mfma_occupancy_blocks(int PW, int WP, int K, size_t smem);
-hipError_t launch_accumulate_mfma(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);
 hipError_t launch_search_split(const AccumPlan& plan, AccumArgs a, hipStream_t st);         // split variant, kernel 1
 hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hipStream_t st);  // split variant, kernel 2 (via launch_accumulate)
-void split_occupancy_blocks(int PW, int WP, int K, size_t smem, bool search_f32, int* search, int* accum);
+void split_occupancy_blocks(int PW, int WP, int K, size_t smem, int* search, int* accum);
 // table may be nullptr (split variant): then only anchor / tablea / cmax are written
 hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
                                double* anchor, float4* tablea, float4* tail, float* cmax, hipStream_t st);

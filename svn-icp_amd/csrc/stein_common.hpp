@@ -1,4 +1,4 @@
-// stein_common.hpp — device helpers shared by the stage-B kernels (stein_iter.hip, stein_mfma.hip).
+// stein_common.hpp — device helpers shared by the stage-B kernels (stein_iter.hip, stein_split.hip).
 #pragma once
 #include "kernels.hpp"
 

@@ -448,7 +448,6 @@ static int occ_t(const AccumPlan& pl) {
   return n > 8 ? 8 : n;
 }
 static int occupancy_blocks(const AccumPlan& pl) {
-  if (pl.f32 == 2) return mfma_occupancy_blocks(pl.PW, pl.WP, pl.K, pl.smem);
   switch (pl.PW) {
     case 8: return occ_t<8, 1>(pl);
     case 16: return occ_t<16, 1>(pl);
@@ -460,9 +459,9 @@ static int occupancy_blocks(const AccumPlan& pl) {
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune) {
   AccumPlan pl{};
   // MFMA tiles: 16 particles wide, 128 candidate rows; correspondence = full keeps the split accumulate kernel for any particle count
-  if (f32 >= 2 && (K > 128 || (n_particles <= 8 && !tune.full_corr))) f32 = 1;
+  if (f32 == 3 && (K > 128 || (n_particles <= 8 && !tune.full_corr))) f32 = 1;
   pl.f32 = f32;
-  int PW = f32 >= 2 ? 16 : 8;
+  int PW = f32 == 3 ? 16 : 8;
   while (PW < 64 && PW < n_particles) PW <<= 1;
   int WP = 1;
   if (PW == 64) { WP = (n_particles + 63) / 64; if (WP >= 3) WP = 4; }
@@ -488,8 +487,7 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
     };
     pl.smem = (size_t)(WB - 1) * per_wg * kNSums * sizeof(double);
     int occ_s = 4, occ_a = 3;
-    pl.search_f32 = tune.search_f32 ? 1 : 0;
-    split_occupancy_blocks(PW, WP, K, pl.smem, pl.search_f32 != 0, &occ_s, &occ_a);
+    split_occupancy_blocks(PW, WP, K, pl.smem, &occ_s, &occ_a);
     if (tune.wgpcu_search >= 1 && tune.wgpcu_search <= 64 && tune.wgpcu_accum >= 1 && tune.wgpcu_accum <= 16) {
       occ_s = tune.wgpcu_search; occ_a = tune.wgpcu_accum;   // profiling knob
     } else {  // measured at C3: the barrier-free search kernel balances best with about four rounds of smaller workgroups
@@ -504,14 +502,13 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
     return pl;
   }
   // bytes per staged source point: baseline = padded f64 row + point; f32 variant = K float4 + point + anchor + C_b
-  const size_t per_pt = f32 == 2 ? (size_t)(2048 + 24 + 24 + 4)
-                       : f32 ? ((size_t)((K + 3) & ~3) * 16 + 24 + 24 + 4) : ((size_t)(pl.RS + 3) * 8);
+  const size_t per_pt = f32 ? ((size_t)((K + 3) & ~3) * 16 + 24 + 24 + 4) : ((size_t)(pl.RS + 3) * 8);
   int TP = pass;
   while (TP < 16) TP += pass;                // at least 16 points per tile …
-  while (TP > pass && (size_t)TP * per_pt > (f32 == 2 ? 36u : f32 ? 32u : 60u) * 1024) TP -= pass;  // … within a modest LDS footprint
+  while (TP > pass && (size_t)TP * per_pt > (f32 ? 32u : 60u) * 1024) TP -= pass;  // … within a modest LDS footprint
   if (tune.tp >= pass && (size_t)tune.tp * per_pt <= 140u * 1024) TP = tune.tp / pass * pass;  // profiling knob
   pl.TP = TP;
-  const size_t tile_bytes = (size_t)TP * per_pt + 4 * 16 + 16 + (f32 == 2 ? 4 * 64 * 20 + 16 : 0);  // + per-wave operand scratch
+  const size_t tile_bytes = (size_t)TP * per_pt + 4 * 16 + 16;
   const size_t red_bytes = (size_t)(WB - 1) * per_wg * kNSums * sizeof(double);
   pl.smem = tile_bytes > red_bytes ? tile_bytes : red_bytes;
   pl.n_tiles = (B + TP - 1) / TP;
@@ -537,7 +534,6 @@ hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, const UpdateArg
   a.Ppad = plan.Ppad;
   a.pts_per_block = plan.pts_per_block; a.spts_per_block = plan.spts_per_block;
   if (plan.f32 == 3) return launch_accumulate_split(plan, a, st);
-  if (plan.f32 == 2) return launch_accumulate_mfma(plan, a, st);
   switch (plan.PW) {
     case 8: return launch_t<8, 1>(plan, a, single, st);
     case 16: return launch_t<16, 1>(plan, a, single, st);

@@ -1,18 +1,18 @@
-// stein_split.hip — Stage B as two kernels per iteration: winner search, then float64 accumulation.
+// stein_split.hip — Stage B as two kernels per iteration: winner search on the bf16 matrix pipe, then float64 accumulation;
+// and k_build_table3, which lays the candidate table out for the search.
 //
-// Same results as the fused kernels (stein_iter.hip, stein_mfma.hip), bit for bit; the split exists
-// for occupancy.  The fused MFMA kernel carries 22 f64 accumulators, the pose and a pending winner
-// next to the MFMA tiles (168 VGPRs, ~2 resident waves per SIMD, VALU busy ~50 %, rocprofv3 PMC in
-// profiles/).  Here
-//   k_stein_search_mfma   finds, for every (source point, particle), the index of the nearest of the
-//                         K candidates (SVGDICP.cpp:300-329 with knn.cu:204-251, K = 1) — float32 MFMA
-//                         scores + rigorous ambiguity test + exact f64 fallback exactly as in
-//                         stein_mfma.hip — and writes one byte per pair; no workgroup barrier, operands
-//                         straight from global memory, ~100 VGPRs;
-//   k_stein_accumulate_w  re-derives Ts in f64, gathers the winner, applies point_filter / weight and
-//                         accumulates the 22 sums (SVGDICP.cpp:331-333, SVNICP.cpp:116-157) with the
-//                         loads of the next two points in flight.
+//   k_stein_search_bf16   finds, for every (source point, particle), the index of the nearest of the K candidates
+//                         (SVGDICP.cpp:300-329 with knn.cu:204-251, K = 1) and writes one byte per pair: float32 scores
+//                         from exact bf16x3 operand splits on v_mfma_f32_16x16x32_bf16, a proven error bound that
+//                         decides whether the pick is the float64 argmin, an exact float64 pass for the undecided pairs;
+//                         no workgroup barrier in the loop, operands straight from global memory, ~112 VGPRs;
+//   k_stein_accumulate_w  re-derives Ts in f64, gathers the winner, applies point_filter / weight and accumulates the 22
+//                         sums (SVGDICP.cpp:331-333, SVNICP.cpp:116-157) with the loads of the next points in flight.
 // Lane ↔ particle in both; the byte array is [B][Ppad] so a wave writes/reads 64 consecutive bytes.
+// Reference kernels of the same contract (tests hold this pair to their correspondences bit for bit):
+// k_stein_accumulate (float64 throughout) and k_stein_accumulate_f32 (float32 VALU search; the product path for shards of
+// <= 8 particles and for K > 128) in stein_iter.hip.  Retired in round 3: the fused f32-MFMA kernel of round 1
+// (stein_mfma.hip) and the f32-operand search kernel — no product configuration reached them.
 #include <cstdlib>
 #include "kernels.hpp"
 #include "stein_common.hpp"
@@ -38,178 +38,7 @@ __device__ __forceinline__ float imax_f(float a, float b) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// search: error bound, packing and ambiguity test are those of stein_mfma.hip (see its header)
-// ---------------------------------------------------------------------------------------------
-// NRB row blocks of 16 candidates go through the matrix cores; with TAIL the (at most four) candidates 16·NRB …
-// 16·NRB+3 are scored by the VALU in the owner lane instead of spending four mostly empty tiles on them (K = 100)
-template <int PW, int WP, int NRB, bool TAIL>
-__global__ __launch_bounds__(NT, 4) void k_stein_search_mfma(AccumArgs a) {
-  if (a.ctl[0]) return;
-  constexpr int BW = kWave / PW;   // source points per wave step (1, 2, 4)
-  constexpr int WB = 4 / WP;       // waves along the source-point axis
-  constexpr int CBP = PW / 16;     // 16-particle column blocks per source point (4, 2, 1)
-  constexpr int NPT = 4 / CBP;     // distinct source points per wave step
-  __shared__ float4 s_scr4[4][64];
-  __shared__ float s_scrb[4][64];
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wave % WP, wb = wave / WP;
-  const int pl = lane % PW, bs = lane / PW;
-  const int mj = lane & 15, mk = lane >> 4;
-  const int pidx = blockIdx.y * (WP * PW) + wp * PW + pl;
-  const int p = a.p_lo + pidx;
-  const bool pvalid = p < a.p_hi;
-
-  double Rt[9], tt[3];
-  {
-    const double* rp = a.Rtot + 12 * (size_t)(pvalid ? p : a.p_lo);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Rt[i] = rp[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) tt[i] = rp[9 + i];
-  }
-  const int K = a.K;
-  float4* scr4 = s_scr4[wave];
-  float* scrb = s_scrb[wave];
-  const float* scr4f = reinterpret_cast<const float*>(scr4);
-  const float kEps = 48.0f * 5.9604644775390625e-08f;
-  const int64_t blk_lo = (int64_t)blockIdx.x * a.spts_per_block;
-  const int64_t blk_hi = (blk_lo + a.spts_per_block < a.B) ? blk_lo + a.spts_per_block : a.B;
-
-  for (int64_t n = blk_lo + wb * BW; n < blk_hi; n += WB * BW) {  // wave-uniform
-    const int64_t b = n + bs;
-    const bool inb = b < blk_hi;
-    const bool valid = pvalid && inb;
-    const int64_t bl = inb ? b : n;
-    const double* sp = a.src + 3 * bl;
-    const double* an = a.anchor + 3 * bl;               // first candidate = origin of the local frame
-    const double s0 = sp[0], s1 = sp[1], s2 = sp[2];
-    const double T0 = (s0 * Rt[0] + s1 * Rt[1] + s2 * Rt[2]) + tt[0];   // SVNICP.cpp:62-64
-    const double T1 = (s0 * Rt[3] + s1 * Rt[4] + s2 * Rt[5]) + tt[1];
-    const double T2 = (s0 * Rt[6] + s1 * Rt[7] + s2 * Rt[8]) + tt[2];
-    const float xf0 = (float)(T0 - an[0]), xf1 = (float)(T1 - an[1]), xf2 = (float)(T2 - an[2]);
-    const float X = __builtin_fmaxf(__builtin_fabsf(xf0), __builtin_fmaxf(__builtin_fabsf(xf1), __builtin_fabsf(xf2)));
-    const float C = a.cmax[bl];
-    const float E = kEps * (C + X) * (C + X);
-    const float beta = __builtin_fmaf(xf0, xf0, __builtin_fmaf(xf1, xf1, xf2 * xf2)) + 4.0f * E;
-    scr4[lane] = make_float4(-2.0f * xf0, -2.0f * xf1, -2.0f * xf2, 1.0f);
-    scrb[lane] = beta;
-
-    float av[NPT][8];
-#pragma unroll
-    for (int q = 0; q < NPT; ++q) {
-      int64_t bq = n + q;
-      bq = bq < blk_hi ? bq : n;
-      const float4* rowp = a.tablea + (size_t)bq * 128 + lane;
-      const float4 alo = rowp[0], ahi = rowp[64];
-      av[q][0] = alo.x; av[q][1] = alo.y; av[q][2] = alo.z; av[q][3] = alo.w;
-      av[q][4] = ahi.x; av[q][5] = ahi.y; av[q][6] = ahi.z; av[q][7] = ahi.w;
-    }
-    __builtin_amdgcn_wave_barrier();
-    float bvv[4], bee[4], b1[4], b2[4];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      bvv[cb] = scr4f[(16 * cb + mj) * 4 + mk];
-      bee[cb] = scrb[16 * cb + mj];
-      b1[cb] = __builtin_huge_valf(); b2[cb] = __builtin_huge_valf();
-    }
-    auto tile = [&](int i) -> v4f {
-      const int cb = i / NRB, rb = i % NRB;
-      const v4f cin = {bee[cb], bee[cb], bee[cb], bee[cb]};
-      return __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb / CBP][rb], bvv[cb], cin, 0, 0, 0);
-    };
-    v4f dcur = tile(0);
-#pragma unroll
-    for (int i = 0; i < 4 * NRB; ++i) {  // tile i+1 goes to the matrix pipe before the VALU consumes tile i
-      v4f dnext = dcur;
-      if (i + 1 < 4 * NRB) dnext = tile(i + 1);
-      const int cb = i / NRB, rb = i % NRB;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float pk = pack_slot(dcur[v], 0x1fu, (unsigned int)(rb * 4 + v));
-        b2[cb] = __builtin_amdgcn_fmed3f(b1[cb], b2[cb], pk);
-        b1[cb] = imin_f(b1[cb], pk);
-      }
-      dcur = dnext;
-    }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) b1[cb] = pack_slot(b1[cb], 0x60u, (unsigned int)mk << 5);
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {  // the four lanes that share a particle
-      float o1[4], o2[4];
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) { o1[cb] = __shfl_xor(b1[cb], off, kWave); o2[cb] = __shfl_xor(b2[cb], off, kWave); }
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        const float hi = imax_f(b1[cb], o1[cb]);
-        b1[cb] = imin_f(b1[cb], o1[cb]);
-        b2[cb] = imin_f(hi, imin_f(b2[cb], o2[cb]));
-      }
-    }
-    float b1own = b1[0], b2own = b2[0];
-#pragma unroll
-    for (int cb = 1; cb < 4; ++cb) {
-      if (mk == cb) { b1own = b1[cb]; b2own = b2[cb]; }
-    }
-    __builtin_amdgcn_wave_barrier();  // scratch is rewritten by the next step
-    if constexpr (TAIL) {
-      const float4* tl = a.tail + (size_t)bl * 4;
-      const float m0 = -2.0f * xf0, m1 = -2.0f * xf1, m2 = -2.0f * xf2;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float4 c = tl[t];  // (c'x, c'y, c'z, |c'|²), a finite sentinel past K
-        const float sc = __builtin_fmaf(c.x, m0, __builtin_fmaf(c.y, m1, __builtin_fmaf(c.z, m2, c.w + beta)));
-        const float pk = pack_slot(sc, 0x7fu, (unsigned int)(NRB * 4 + t));  // slot of candidate 16·NRB + t, lane group 0
-        b2own = __builtin_amdgcn_fmed3f(b1own, b2own, pk);
-        b1own = imin_f(b1own, pk);
-      }
-    }
-
-    const unsigned int wbits = __float_as_uint(b1own);
-    int kb = (int)(((wbits & 0x1cu) << 2) | ((wbits >> 3) & 0xcu) | (wbits & 3u));  // 16·rb + 4·mk + v
-    const float thr = 2.0f * E + 6.103515625e-05f * b2own + 1.0e-30f;
-    const bool ambiguous = valid && (!(b2own - b1own > thr) || kb >= K);
-    kb = kb < K ? kb : 0;
-    unsigned long long am = __ballot(ambiguous);
-    if (am) {  // rare: exact f64 nearest-of-K for the undecided lanes, candidate-parallel across the wave
-      if (a.ambig_count && lane == 0) atomicAdd(a.ambig_count, 1);
-      do {
-        const int L = (int)__builtin_ctzll(am);
-        am &= am - 1;
-        const double t0 = rdlane_f64(T0, L), t1 = rdlane_f64(T1, L), t2 = rdlane_f64(T2, L);
-        const int bsL = L / PW;
-        const int32_t* ci = a.cand + (size_t)(n + bsL) * K;
-        double bd = __builtin_huge_val(), d_first = 0.0;
-        int bk = 0x7fffffff;
-        for (int k = lane; k < K; k += kWave) {
-          int64_t ti = ci[k];
-          ti = ti < 0 ? 0 : (ti >= a.M ? a.M - 1 : ti);
-          const double* r = a.tgt + 3 * ti;
-          const double dx = t0 - r[0], dy = t1 - r[1], dz = t2 - r[2];
-          const double d = (dx * dx + dy * dy) + dz * dz;   // knn_cpu.cpp:43-50 order, unfused
-          if (k == 0) d_first = d;
-          if (d < bd || (d == bd && k < bk)) { bd = d; bk = k; }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          const double od = __shfl_xor(bd, off, kWave);
-          const int ok = __shfl_xor(bk, off, kWave);
-          if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
-        }
-        // the serial reference loop starts from candidate 0 and only replaces on '<': a NaN first
-        // distance is never replaced, and an all-NaN row keeps index 0
-        const double d0 = rdlane_f64(d_first, 0);
-        const int ke = (d0 != d0 || bk == 0x7fffffff) ? 0 : bk;
-        if (lane == L) kb = ke;
-      } while (am);
-    }
-    if (inb) a.kbest[(size_t)b * a.Ppad + pidx] = (uint8_t)kb;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// search on the bf16 matrix pipe (default): same scores, same ambiguity test, same exact fallback
+// search on the bf16 matrix pipe
 // ---------------------------------------------------------------------------------------------
 // Measured on gfx950 (tests/microbench/search_loop.hip, valu_ops.hip): v_mfma_f32_16x16x4_f32 holds the SIMD's
 // vector issue for all of its 32 cycles (tile = 32 + tracking, nothing overlaps), while v_mfma_f32_16x16x32_bf16
@@ -769,13 +598,74 @@ __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulat
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// candidate table of the search kernel: one wave per source point.  Candidates relative to the point's first candidate as
+// float32 (c'x, c'y, c'z, |c'|²) in MFMA A-operand order (lane = 16·component + candidate mod 16, one float4 per four 16-row
+// blocks; rows past K are finite sentinels), the origin of the local frame, C_b = max |c'|₂ rounded up (the error bound's
+// C2) and candidates 96…99 for the owner-lane tail.  Replaces the I copies of target_batch [B,K,3] of SVGDICP.cpp:191-198.
+// ---------------------------------------------------------------------------------------------
+constexpr float kSentinelCC = 1.0e30f; // padded rows: finite, so packed words never become NaN patterns
+__global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict__ idx, int64_t B, int K,
+                                                      const double* __restrict__ tgt, int64_t M, double* __restrict__ table,
+                                                      double* __restrict__ anchor, float4* __restrict__ tablea,
+                                                      float4* __restrict__ tail, float* __restrict__ cmax) {
+  __shared__ float rowbuf[4][128 * 4];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  if (b >= B) return;  // whole wave
+  int64_t i0 = idx[b * K];
+  i0 = i0 < 0 ? 0 : (i0 >= M ? M - 1 : i0);  // clamped: a corrupted candidate list must never become a wild gather
+  const double a0 = tgt[3 * i0], a1 = tgt[3 * i0 + 1], a2 = tgt[3 * i0 + 2];
+  float cm = 0.0f;
+  float* rb = rowbuf[wave];
+  for (int k = lane; k < 128; k += kWave) {
+    float cx = 0.f, cy = 0.f, cz = 0.f, cc = kSentinelCC;
+    if (k < K) {
+      int64_t i = idx[b * K + k];
+      i = i < 0 ? 0 : (i >= M ? M - 1 : i);
+      const double x = tgt[3 * i], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
+      if (table) {
+        double* o = table + ((size_t)b * K + k) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+      }
+      cx = (float)(x - a0); cy = (float)(y - a1); cz = (float)(z - a2);
+      cc = (float)(((double)cx * cx + (double)cy * cy) + (double)cz * cz);
+      // C_b = max |c'|_2 over the point's candidates, rounded up (>= max |c'|_inf, which is all the f32 kernels' bounds need;
+      // the bf16 search kernel's bound is written in the 2-norm, stein_split.hip)
+      cm = __builtin_fmaxf(cm, (float)sqrt(((double)cx * cx + (double)cy * cy) + (double)cz * cz) * 1.0000002f);
+      if (!(cc < kSentinelCC)) cm = __builtin_nanf("");  // huge or NaN rows: every step of this point takes the exact path
+    }
+    rb[4 * k] = cx; rb[4 * k + 1] = cy; rb[4 * k + 2] = cz; rb[4 * k + 3] = cc;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(cm, off, kWave);
+    cm = (cm != cm || o != o) ? __builtin_nanf("") : __builtin_fmaxf(cm, o);
+  }
+  if (lane == 0) {
+    cmax[b] = cm;
+    anchor[3 * b] = a0; anchor[3 * b + 1] = a1; anchor[3 * b + 2] = a2;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (tail && lane < 4) tail[(size_t)b * 4 + lane] = make_float4(rb[4 * (96 + lane)], rb[4 * (96 + lane) + 1], rb[4 * (96 + lane) + 2], rb[4 * (96 + lane) + 3]);
+  const int mi = lane & 15, mk = lane >> 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float4 v;
+    v.x = rb[4 * (16 * (4 * h + 0) + mi) + mk];
+    v.y = rb[4 * (16 * (4 * h + 1) + mi) + mk];
+    v.z = rb[4 * (16 * (4 * h + 2) + mi) + mk];
+    v.w = rb[4 * (16 * (4 * h + 3) + mi) + mk];
+    tablea[((size_t)b * 2 + h) * 64 + lane] = v;
+  }
+}
+
+
 // (row blocks, tail) with an instantiation: K <= 16, 32, 64, 96, 100 (96 + four VALU candidates), 112, 128
 inline int row_code_for(int K) { return K <= 16 ? 1 : K <= 32 ? 2 : K <= 64 ? 4 : K <= 96 ? 6 : K <= 100 ? 60 : K <= 112 ? 7 : 8; }
 
 template <int PW, int WP, int NRB, bool TAIL>
 hipError_t launch_s(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
-  if (plan.search_f32) hipLaunchKernelGGL((k_stein_search_mfma<PW, WP, NRB, TAIL>), dim3(plan.sgrid_x, plan.grid_y), dim3(NT), 0, st, a);
-  else hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL>), dim3(plan.sgrid_x, plan.grid_y), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL((k_stein_search_bf16<PW, WP, NRB, TAIL>), dim3(plan.sgrid_x, plan.grid_y), dim3(NT), 0, st, a);
   return hipGetLastError();
 }
 template <int PW, int WP>
@@ -799,22 +689,21 @@ hipError_t launch_w(const AccumPlan& plan, const AccumArgs& a, hipStream_t st) {
 }
 
 template <int PW, int WP, int NRB, bool TAIL>
-hipError_t occ_search(bool f32, int* n) {
-  return f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_stein_search_mfma<PW, WP, NRB, TAIL>, NT, 0)
-             : hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_stein_search_bf16<PW, WP, NRB, TAIL>, NT, 0);
+hipError_t occ_search(int* n) {
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_stein_search_bf16<PW, WP, NRB, TAIL>, NT, 0);
 }
 template <int PW, int WP>
-void occ_split(int K, size_t smem, bool f32, int* search, int* accum) {
+void occ_split(int K, size_t smem, int* search, int* accum) {
   int n = 0;
   hipError_t e;
   switch (row_code_for(K)) {
-    case 1: e = occ_search<PW, WP, 1, false>(f32, &n); break;
-    case 2: e = occ_search<PW, WP, 2, false>(f32, &n); break;
-    case 4: e = occ_search<PW, WP, 4, false>(f32, &n); break;
-    case 6: e = occ_search<PW, WP, 6, false>(f32, &n); break;
-    case 60: e = occ_search<PW, WP, 6, true>(f32, &n); break;
-    case 7: e = occ_search<PW, WP, 7, false>(f32, &n); break;
-    default: e = occ_search<PW, WP, 8, false>(f32, &n); break;
+    case 1: e = occ_search<PW, WP, 1, false>(&n); break;
+    case 2: e = occ_search<PW, WP, 2, false>(&n); break;
+    case 4: e = occ_search<PW, WP, 4, false>(&n); break;
+    case 6: e = occ_search<PW, WP, 6, false>(&n); break;
+    case 60: e = occ_search<PW, WP, 6, true>(&n); break;
+    case 7: e = occ_search<PW, WP, 7, false>(&n); break;
+    default: e = occ_search<PW, WP, 8, false>(&n); break;
   }
   *search = (e != hipSuccess || n < 1) ? 4 : (n > 8 ? 8 : n);
   n = 0;
@@ -825,16 +714,25 @@ void occ_split(int K, size_t smem, bool f32, int* search, int* accum) {
 }  // namespace
 
 // resident workgroups per CU of the two kernels (grids are sized to one resident round)
-void split_occupancy_blocks(int PW, int WP, int K, size_t smem, bool search_f32, int* search, int* accum) {
+void split_occupancy_blocks(int PW, int WP, int K, size_t smem, int* search, int* accum) {
   switch (PW) {
-    case 16: return occ_split<16, 1>(K, smem, search_f32, search, accum);
-    case 32: return occ_split<32, 1>(K, smem, search_f32, search, accum);
+    case 16: return occ_split<16, 1>(K, smem, search, accum);
+    case 32: return occ_split<32, 1>(K, smem, search, accum);
     default:
-      if (WP == 1) return occ_split<64, 1>(K, smem, search_f32, search, accum);
-      if (WP == 2) return occ_split<64, 2>(K, smem, search_f32, search, accum);
-      return occ_split<64, 4>(K, smem, search_f32, search, accum);
+      if (WP == 1) return occ_split<64, 1>(K, smem, search, accum);
+      if (WP == 2) return occ_split<64, 2>(K, smem, search, accum);
+      return occ_split<64, 4>(K, smem, search, accum);
   }
 }
+
+hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
+                               double* anchor, float4* tablea, float4* tail, float* cmax, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_build_table3, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, idx, B, K, tgt, M, table, anchor, tablea,
+                     tail, cmax);
+  return hipGetLastError();
+}
+
 
 // search kernel, then (launch_accumulate_split) the accumulation kernel; api.hip brackets them separately
 hipError_t launch_search_split(const AccumPlan& plan, AccumArgs a, hipStream_t st) {

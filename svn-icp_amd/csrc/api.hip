@@ -68,6 +68,7 @@ struct svnicp_ctx {
   DevBuf<float> txf, tyf, tzf, cmaxb;
   DevBuf<float4> tablef, tablea, tail;
   DevBuf<uint8_t> kbest;
+  DevBuf<int32_t> kidx;
   // source-row sharding (svnicp_set_row_shard): this context holds rows of a larger scan; its per-iteration sums are one of
   // row_world partial records that the host all-gathers into rank_sums [row_world][P][22]
   int row_rank = 0, row_world = 1;
@@ -253,7 +254,7 @@ void svnicp_destroy(svnicp_ctx* c) {
   c->eul.release(); c->opt.release(); c->uctl.release(); c->rank_sums.release(); c->stage_fail_count.release(); c->stage_fail_list.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
   c->full_q.release(); c->full_d2.release(); c->full_idx.release(); c->arena.release(); c->chunk_tab.release();
-  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->tail.release(); c->kbest.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->tail.release(); c->kbest.release(); c->kidx.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   if (c->dbg_phase) (void)hipFree(c->dbg_phase);
   if (c->dbg_upd) (void)hipFree(c->dbg_upd);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -525,7 +526,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
   }
   if (c->plan.f32 != 3) HIPCHK(c, c->table.ensure((size_t)B * c->K * 3));  // the split variant gathers from the target cloud
   if (c->plan.f32 == 3) { HIPCHK(c, c->tablea.ensure((size_t)B * 128)); HIPCHK(c, c->anchor.ensure((size_t)B * 3)); HIPCHK(c, c->tail.ensure((size_t)B * 4)); }
-  if (c->plan.f32 == 3) HIPCHK(c, c->kbest.ensure((size_t)B * c->plan.Ppad));
+  if (c->plan.f32 == 3) { HIPCHK(c, c->kbest.ensure((size_t)B * c->plan.Ppad)); HIPCHK(c, c->kidx.ensure((size_t)B * c->plan.Ppad)); }
   else HIPCHK(c, c->tablef.ensure((size_t)B * c->K));
   if (c->prm.record_trace) {
     HIPCHK(c, c->trcorr.ensure((size_t)I * P * B));
@@ -746,7 +747,7 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   const int nshard = c->p_hi - c->p_lo;
   if (nshard <= 0) return SVNICP_OK;
   AccumArgs a{};
-  a.src = c->src.p; a.table = c->table.p; a.tablef = c->tablef.p; a.tablea = c->tablea.p; a.kbest = c->kbest.p; a.tgt = c->tgt.p; a.cand = c->cand_idx.p; a.anchor = c->anchor.p; a.tail = c->tail.p; a.M = c->M; a.cmax = c->cmaxb.p; a.ambig_count = c->ambig.p;
+  a.src = c->src.p; a.table = c->table.p; a.tablef = c->tablef.p; a.tablea = c->tablea.p; a.kbest = c->kbest.p; a.kidx = c->kidx.p; a.tgt = c->tgt.p; a.cand = c->cand_idx.p; a.anchor = c->anchor.p; a.tail = c->tail.p; a.M = c->M; a.cmax = c->cmaxb.p; a.ambig_count = c->ambig.p;
   a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K;
   a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
   a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;

@@ -130,7 +130,9 @@ struct AccumArgs {
   const double* anchor; // [B][3] = tgt[cand[b][0]]
   const float4* tail;   // [B][4] float32 local rows of candidates 96..99 (K in 97..100: scored by the VALU, see stein_split.hip)
   int64_t M;
-  uint8_t* kbest;       // split variant: winner index per (source point, particle of the shard), [B][Ppad]
+  uint8_t* kbest;       // split variant: winner slot per (source point, particle of the shard), [B][Ppad]
+  int32_t* kidx;        // … and the winner's TARGET index cand[b][slot], [B][Ppad]: the accumulate kernel's gather then starts one
+                        // dependent load later (byte -> index -> coordinates becomes index -> coordinates)
   const int32_t* full_idx;  // correspondence = full: nearest target index of every (particle, source point), [P][B]; else nullptr
   int pts_per_block, spts_per_block;  // split variant: source points per workgroup (accumulate / search kernel)
   unsigned int* ticket;               // fused one-particle iteration: arrival counter of the accumulate kernel's workgroups

@@ -218,6 +218,9 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
   __syncthreads();
   const int64_t nfirst = blk_lo + wave * BW;
 
+  int pend_idx = 0;       // winner's target index of the previous step, stored one step late (see the end of the step)
+  size_t pend_off = 0;
+  bool pend_have = false;
   v4f alo_n, ahi_n;   // PIPE: table rows of the NEXT step, in flight while this step's tiles run
   if constexpr (PIPE) {
     const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)(nfirst < blk_hi ? nfirst : blk_lo) * 128 + lane;
@@ -403,11 +406,21 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
           } while (am);
         }
       }
-      if (inb) a.kbest[(size_t)b * a.Ppad + (pbase + pin)] = (uint8_t)kb;
+      // the winner's slot byte, and its target index for the accumulate kernel (one dependent load less over there).  The
+      // index is a scattered load: it is STORED one step later, so that its latency hides behind the next step's tiles
+      // (an undecided pair's two entries are rewritten by the exact pass)
+      if (pend_have) a.kidx[pend_off] = pend_idx;
+      pend_have = inb;
+      if (inb) {
+        pend_off = (size_t)b * a.Ppad + (pbase + pin);
+        a.kbest[pend_off] = (uint8_t)kb;
+        pend_idx = a.cand[(size_t)b * K + kb];
+      }
     }
     __builtin_amdgcn_wave_barrier();  // scratch is rewritten by the next step
   }
 
+  if (pend_have) a.kidx[pend_off] = pend_idx;
   // exact pass over the queued pairs: 32 lanes per pair, all waves of the workgroup, no lane waits for another pair
   __syncthreads();
   {
@@ -421,7 +434,10 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
       const int64_t be = blk_lo + (int64_t)(ent >> 8);
       const int pin = (int)(ent & 0xffu);
       const int ke = exact_nearest_of_k<kExactLanes>(a, s_pose[pin / PW], be, pin % PW, K, sub);
-      if (sub == 0) a.kbest[(size_t)be * a.Ppad + (pbase + pin)] = (uint8_t)ke;
+      if (sub == 0) {
+        a.kbest[(size_t)be * a.Ppad + (pbase + pin)] = (uint8_t)ke;
+        a.kidx[(size_t)be * a.Ppad + (pbase + pin)] = a.cand[(size_t)be * K + ke];
+      }
     }
     if (tid == 0 && a.ambig_count && s_qsteps) { atomicAdd(a.ambig_count, (int)s_qsteps); atomicAdd(a.ambig_count + 1, (int)s_qn); }
   }
@@ -469,16 +485,18 @@ __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulat
   const SVNICP_CONST_AS int32_t* ccand = (const SVNICP_CONST_AS int32_t*)a.cand;
   const SVNICP_CONST_AS double* ctgt = (const SVNICP_CONST_AS double*)a.tgt;
   const uint8_t* kbp = a.kbest + pidx;
+  const int32_t* kip = a.kidx + pidx;   // PLAIN: the winner's target index, written by the search kernel
 
   // per trip: winner bytes of the NEXT trip's U points | target indices | winner coordinates | sums — each batch of loads
   // is requested back to back, so a trip pays the byte -> index -> coordinates chain once for U points, and nothing is
   // carried between trips except the U prefetched bytes (no rotating copies).  Rows are clamped, never predicated: a
   // point past the block only changes `on`.
   const int32_t* fullp = (!PLAIN && a.full_idx) ? a.full_idx + (size_t)(pvalid ? p : a.p_lo) * a.B : nullptr;
-  auto load_kb = [&](int64_t n) -> int {   // winner byte; correspondence = full: the target index itself
+  auto load_kb = [&](int64_t n) -> int {   // PLAIN: the winner's target index; else the winner byte (correspondence = full: the target index itself)
     const int64_t b = n + bs;
     const int64_t bc = b < blk_hi ? b : blk_lo;
-    if (!PLAIN && fullp) return fullp[bc];
+    if (PLAIN) return kip[(size_t)bc * a.Ppad];
+    if (fullp) return fullp[bc];
     return (int)kbp[(size_t)bc * a.Ppad];
   };
   // The reference zeroes a rejected row by multiplying with the mask (SVGDICP.cpp:331-333): e = 0, |e| = 0, so w = 1 and
@@ -547,7 +565,7 @@ __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulat
       kb[u] = kbn[u];
       const int64_t b = n + u * STEP + bs;
       const int64_t bl = b < blk_hi ? b : blk_lo;
-      const int64_t t = (!PLAIN && fullp) ? (int64_t)kb[u] : (int64_t)ccand[(size_t)bl * K + kb[u]];
+      const int64_t t = (PLAIN || fullp) ? (int64_t)kb[u] : (int64_t)ccand[(size_t)bl * K + kb[u]];
       ti[u] = t < 0 ? 0 : (t >= a.M ? a.M - 1 : t);
     }
 #pragma unroll

@@ -93,7 +93,10 @@ int svnicp_set_stream(svnicp_ctx *ctx, void *hip_stream);
 int svnicp_synchronize(svnicp_ctx *ctx);
 
 /* SVGDICP::add_cloud(source[B,3], target[M,3], init_pose[6,P,1]) — src/core/SVGDICP.cpp:46-62.
- * Split in two because the clouds and the particles are independent buffers; both are copied. */
+ * Split in two because the clouds and the particles are independent buffers; both are copied.  SVNICP_MEM_HOST: the
+ * caller's buffer is free when the call returns.  SVNICP_MEM_DEVICE: the copy is QUEUED on the context's stream — the
+ * device buffer must stay unchanged until svnicp_align has returned (or svnicp_synchronize).  svnicp_set_particles stages
+ * the poses through pinned memory and does not wait for the stream either. */
 int svnicp_set_clouds(svnicp_ctx *ctx, const double *src_xyz, int64_t B, const double *tgt_xyz,
                       int64_t M, int mem_kind);
 int svnicp_set_particles(svnicp_ctx *ctx, const double *init_pose6xP, int P);

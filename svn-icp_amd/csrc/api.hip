@@ -45,8 +45,14 @@ struct svnicp_ctx {
   // second queue: the pair statistics of the Stein step (they need the poses only) run here, beside the stage-B kernels of
   // the same iteration; forked from and joined into `stream` with events, so the caller still sees one ordered queue
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_init = nullptr;
+  bool init_in_flight = false;
   bool median_pending = false;
+  // pinned host staging: the initial particles go up and the result block (mean, variance, covariance, weights) comes down
+  // without a stream synchronisation of their own
+  double* h_init = nullptr; size_t h_init_cap = 0;
+  double* h_stats = nullptr; size_t h_stats_cap = 0;
+  bool host_stats_valid = false;   // h_stats holds the last registration's results (after the stream has been synchronised)
   int single_done_it = -1;   // iteration whose Stein step the accumulate kernel's last workgroup has already enqueued (P = 1)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   std::string err;
@@ -212,7 +218,8 @@ int svnicp_create(const svnicp_params* params, int device, const double* init_po
   c->stream = c->own_stream;
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess) {
     svnicp_destroy(c);
     return fail(nullptr, SVNICP_ERR_HIP, "svnicp_create: hipStreamCreate / hipEventCreate failed");
   }
@@ -245,8 +252,11 @@ void svnicp_destroy(svnicp_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->h_init) (void)hipHostFree(c->h_init);
+  if (c->h_stats) (void)hipHostFree(c->h_stats);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_init) (void)hipEventDestroy(c->ev_init);
   DevBuf<double>* dbl[] = {&c->src, &c->tgt, &c->tx, &c->ty, &c->tz, &c->pool_d, &c->cand_d2, &c->table,
                            &c->init_pose, &c->R, &c->t, &c->Rtot, &c->pose_out, &c->sums, &c->partial, &c->work,
                            &c->stats, &c->trH, &c->trb, &c->trN, &c->trphi, &c->trh};
@@ -275,6 +285,7 @@ int svnicp_synchronize(svnicp_ctx* c) {
   CTX_CHECK(c);
   if (bind(c)) return SVNICP_ERR_HIP;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->have_result && c->h_stats) c->host_stats_valid = true;   // svnicp_finish's copy of the result block has landed
   return SVNICP_OK;
 }
 
@@ -335,7 +346,24 @@ int svnicp_set_particles(svnicp_ctx* c, const double* init, int P) {
   HIPCHK(c, c->eul.ensure((size_t)P * 6));
   HIPCHK(c, c->opt.ensure((size_t)P * 18));
   HIPCHK(c, c->uctl.ensure(update_uctl_doubles(P)));
-  HIPCHK(c, hipMemcpyAsync(c->init_pose.p, init, (size_t)P * 48, hipMemcpyHostToDevice, c->stream));
+  // through pinned staging: the caller's buffer is free when this returns and the stream is not synchronised (a second
+  // call before the first copy has run would overwrite the staging area: wait for the stream only then)
+  if ((size_t)P * 6 > c->h_init_cap || (size_t)P + 48 > c->h_stats_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_init) (void)hipHostFree(c->h_init);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
+    c->h_init = c->h_stats = nullptr; c->h_init_cap = c->h_stats_cap = 0;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_init), (size_t)P * 48, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_stats), ((size_t)P + 48) * 8, hipHostMallocDefault));
+    c->h_init_cap = (size_t)P * 6; c->h_stats_cap = (size_t)P + 48;
+  } else if (c->init_in_flight) {
+    HIPCHK(c, hipEventSynchronize(c->ev_init));
+  }
+  std::memcpy(c->h_init, init, (size_t)P * 48);
+  HIPCHK(c, hipMemcpyAsync(c->init_pose.p, c->h_init, (size_t)P * 48, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_init, c->stream));
+  c->init_in_flight = true;
+  c->host_stats_valid = false;
   const bool first = !c->particles_set || P != c->P;
   if (first && c->row_world > 1) { c->row_world = 1; c->row_rank = 0; c->B_total = 0; }   // the record array is sized by P: set the row shard again
   c->P = P;
@@ -344,7 +372,6 @@ int svnicp_set_particles(svnicp_ctx* c, const double* init, int P) {
   // add_cloud semantics: R_, t_ are reset, pose_particles_ is left alone (SVGDICP.cpp:46-62)
   HIPCHK(c, launch_init_particles(c->init_pose.p, P, c->pose0, c->prm.mode, c->R.p, c->t.p, c->Rtot.p, c->pose_out.p,
                                   (first || c->prm.mode == SVNICP_MODE_SVN) ? 1 : 0, c->eul.p, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->particles_set = true;
   c->particles_dirty = true;
   return SVNICP_OK;
@@ -830,6 +857,10 @@ int svnicp_finish(svnicp_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   StatsArgs s{c->pose_out.p, c->P, c->prm.mode, c->stats.p};
   HIPCHK(c, launch_stats(s, c->stream));
+  // the result block follows the kernels down the stream into pinned memory: the getters then cost no GPU round trip
+  c->host_stats_valid = false;
+  if (c->h_stats && (size_t)c->P + 48 <= c->h_stats_cap)
+    HIPCHK(c, hipMemcpyAsync(c->h_stats, c->stats.p, ((size_t)c->P + 48) * 8, hipMemcpyDeviceToHost, c->stream));
   c->have_result = true;
   c->timing_valid = true;
   return SVNICP_OK;
@@ -871,6 +902,7 @@ int svnicp_align(svnicp_ctx* c) {
   int rc = svnicp_align_async(c);
   if (rc) return rc;  // negative status, or SVNICP_NO_OPTIMIZER
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->host_stats_valid = c->h_stats != nullptr;
   return SVNICP_ALIGN_SUCCESS;
 }
 
@@ -886,12 +918,17 @@ static int fetch(svnicp_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!(c)->have_result) return fail((c), SVNICP_ERR_INVALID, "no registration result yet"); \
   } while (0)
 
-int svnicp_get_transformation(svnicp_ctx* c, double out6[6]) { NEED_RESULT(c); return fetch(c, out6, c->stats.p, 48); }
-int svnicp_get_distribution(svnicp_ctx* c, double out6[6]) { NEED_RESULT(c); return fetch(c, out6, c->stats.p + 6, 48); }
-int svnicp_get_cov_matrix(svnicp_ctx* c, double out36[36]) { NEED_RESULT(c); return fetch(c, out36, c->stats.p + 12, 288); }
+// mean[6] var[6] cov[36] weights[P]: from the pinned copy svnicp_finish queued when it has landed, else from the device
+static int fetch_stats(svnicp_ctx* c, void* dst, size_t off_doubles, size_t n_doubles) {
+  if (c->host_stats_valid) { std::memcpy(dst, c->h_stats + off_doubles, n_doubles * 8); return SVNICP_OK; }
+  return fetch(c, dst, c->stats.p + off_doubles, n_doubles * 8);
+}
+int svnicp_get_transformation(svnicp_ctx* c, double out6[6]) { NEED_RESULT(c); return fetch_stats(c, out6, 0, 6); }
+int svnicp_get_distribution(svnicp_ctx* c, double out6[6]) { NEED_RESULT(c); return fetch_stats(c, out6, 6, 6); }
+int svnicp_get_cov_matrix(svnicp_ctx* c, double out36[36]) { NEED_RESULT(c); return fetch_stats(c, out36, 12, 36); }
 int svnicp_get_particle_weight(svnicp_ctx* c, double* outP) {
   NEED_RESULT(c);
-  return fetch(c, outP, c->stats.p + 48, (size_t)c->P * 8);
+  return fetch_stats(c, outP, 48, (size_t)c->P);
 }
 int svnicp_get_particles(svnicp_ctx* c, double* out6P) {
   CTX_CHECK(c);

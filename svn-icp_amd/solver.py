@@ -140,7 +140,9 @@ class _SolverBase:
             self._keep = (src, tgt)
             B, M = src.shape[0], tgt.shape[0]
             rc = self._L.svnicp_set_clouds(self._h, C.c_void_p(src.data_ptr()), B, C.c_void_p(tgt.data_ptr()), M, 1)
-            self._check(rc, "svnicp_set_clouds")      # the copies are complete when svnicp_set_particles below returns (it waits for the stream)
+            self._check(rc, "svnicp_set_clouds")      # device-to-device copies queued on the library's stream; self._keep holds the
+            #                                           tensors until the next add_cloud, and the caller must not write to them
+            #                                           before stein_align has returned (include/svnicp_hip.h, svnicp_set_clouds)
         else:
             src = np.ascontiguousarray(np.asarray(new_cloud, np.float64).reshape(-1, 3))
             tgt = np.ascontiguousarray(np.asarray(target, np.float64).reshape(-1, 3))

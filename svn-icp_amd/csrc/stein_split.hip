@@ -455,7 +455,10 @@ __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulat
   if (a.ctl[0]) return;
   constexpr int BW = kWave / PW;
   constexpr int WB = 4 / WP;
-  constexpr int U = 4;             // points per wave and loop trip: their three dependent loads go out as three batches
+#ifndef SVNICP_ACCUM_U
+#define SVNICP_ACCUM_U 4
+#endif
+  constexpr int U = SVNICP_ACCUM_U;   // points per wave and loop trip: their dependent loads go out as batches (2, 6, 8 measured: no better)
   extern __shared__ __align__(16) double lds[];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);

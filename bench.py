@@ -239,10 +239,10 @@ def main():
             # only the algorithmic bytes and the brute-force pair count are reported for it
             "stage_a_knn": dict(bytes=24.0 * (B + M) + 12.0 * B * K, pairs_bruteforce=float(B) * M),
             # split stage B: the search kernel reads the float32 candidate rows (16 B each) and the source points and
-            # writes one winner byte per (point, particle); the accumulate kernel reads the bytes, the source points
-            # and one winner (24 B) per pair.  Fused variants: everything is in the k_stein_accumulate class.
-            "k_stein_search": dict(bytes=16.0 * B * K + 24.0 * B + 1.0 * P * B, flops=8.0 * P * B * K),
-            "k_stein_accumulate": dict(bytes=(24.0 * B + 25.0 * P * B) if split else (24.0 * B + 24.0 * B * K),
+            # writes the winner's slot byte and target index (5 B) per (point, particle); the accumulate kernel reads
+            # the index (4 B), the source points and one winner (24 B) per pair.  Fused kernels: all in k_stein_accumulate.
+            "k_stein_search": dict(bytes=16.0 * B * K + 24.0 * B + 5.0 * P * B, flops=8.0 * P * B * K),
+            "k_stein_accumulate": dict(bytes=(24.0 * B + 28.0 * P * B) if split else (24.0 * B + 24.0 * B * K),
                                        flops=(60.0 * P * B) if split else 8.0 * P * B * K),
         }
         traffic = {}

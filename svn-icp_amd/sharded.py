@@ -20,10 +20,10 @@ the per-iteration pass (transform → nearest-of-K → Gauss–Newton sums) over
 After the all-gather every rank runs the small Stein update redundantly on all P particles
 (svnicp_iter_update) — identical inputs and code, so no broadcast or reduction collective is needed.
 
-The compute backend is the HIP library through the split-phase C ABI (HipBackend).  The class
-takes a ``backend`` argument only so that the orchestration can be exercised by the CPU tests
-(world_size 2, gloo) with a test-side backend; the product never constructs anything else and
-HipBackend raises when libsvnicp_hip.so or a gfx950 device is missing.
+The compute backend is the HIP library through the split-phase C ABI (HipBackend, made by
+``_make_backend``); it raises when libsvnicp_hip.so or a gfx950 device is missing.  The CPU tests
+(gloo ranks) exercise the orchestration with a SUBCLASS of their own that overrides ``_make_backend``
+(tests/oracle_backend.py) — nothing in this module knows about it.
 """
 from __future__ import annotations
 
@@ -151,8 +151,7 @@ class ShardedSVNICP:
 
     _solver_cls = SVNICP
 
-    def __init__(self, param: SteinICPParam, init_pose, group=None, device_index: int | None = None, backend=None,
-                 split="rows"):
+    def __init__(self, param: SteinICPParam, init_pose, group=None, device_index: int | None = None, split="rows"):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -169,13 +168,16 @@ class ShardedSVNICP:
             if self.Wp * self.Wb != self.world:
                 raise ValueError(f"split {split} does not match the world size {self.world}")
         self.rp, self.rb = self.rank % self.Wp, self.rank // self.Wp
-        if backend is None:
-            import torch
-            if device_index is None:
-                device_index = torch.cuda.current_device()
-            backend = HipBackend(param, init_pose, device_index, self._solver_cls)
-        self.be = backend
+        self.be = self._make_backend(param, init_pose, device_index)
         self.B_total = 0
+
+    def _make_backend(self, param, init_pose, device_index):
+        """The compute backend of this rank: the HIP library through the split-phase C ABI — there is no other in the product
+        (HipBackend raises without libsvnicp_hip.so or a gfx950 device)."""
+        import torch
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        return HipBackend(param, init_pose, device_index, self._solver_cls)
 
     def add_cloud(self, src, tgt, init_pose):
         """add_cloud of the reference (SVGDICP.cpp:46-62).  With source rows sharded the backend is handed this rank's row

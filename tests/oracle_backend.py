@@ -92,3 +92,12 @@ class OracleBackend:
 
     def synchronize(self):
         pass
+
+
+def oracle_sharded(base_cls, orc):
+    """A subclass of svnicp_amd.sharded.ShardedSVNICP whose ranks compute with the CPU oracle (test infrastructure: the
+    product class only ever builds the HIP backend)."""
+    class OracleSharded(base_cls):
+        def _make_backend(self, param, init_pose, device_index):
+            return OracleBackend(orc, param, init_pose)
+    return OracleSharded

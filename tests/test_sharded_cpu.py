@@ -22,7 +22,7 @@ def _free_port():
 def _worker(rank, world, port, case, out_dir, split):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import __graft_entry__ as graft
-    from oracle_backend import OracleBackend
+    from oracle_backend import oracle_sharded
     pkg = graft.load_package(); orc = graft.load_oracle()
     orc.set_threads(2)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -33,7 +33,7 @@ def _worker(rank, world, port, case, out_dir, split):
     init = pkg.scans.make_particles(P, seed=17) * 0.3
     prm = pkg.SteinICPParam(iterations=I, lr=1.0, max_dist=1.0, KNN_count=K, SVN_full_grad=full, check_early_stop=es,
                             convergence_threshold=thr)
-    s = ShardedSVNICP(prm, init, backend=OracleBackend(orc, prm, init), split=split)
+    s = oracle_sharded(ShardedSVNICP, orc)(prm, init, split=split)
     assert s.world == world and s.rank == rank
     s.add_cloud(src, tgt, init)
     T = np.eye(4); T[:3, 3] = [0.01, -0.02, 0.005]

@@ -114,12 +114,15 @@ __device__ __forceinline__ bf8 split_b3(float x) {   // [b1 b2 | b3 b1 | b2 b1 |
 __device__ __forceinline__ float pack_slot3(float v, unsigned int bits) {  // (v & ~31) | bits in one full-rate op
   return __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(v), 31u, bits, 0xBA));
 }
-// min / max / median of packed scores of either sign, as the instruction computes them (no canonicalising copies: a
-// NaN score only ever comes with a NaN error bound, and that sends the pair to the exact pass)
-__device__ __forceinline__ float fmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float fmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float fmed3_raw(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float fmin3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// min / max / median of scores of either sign.  Compiler-visible operations, not inline assembly: the result registers of a
+// matrix instruction need software wait states before a vector instruction may read them, and the compiler's hazard
+// recognizer does not look inside an asm statement (a v_min3_f32 written in asm read stale registers: 44 % of the pairs came
+// out "undecided").  IEEE-2019 minimum / maximum (v_minimum3_f32 / v_maximum3_f32 on gfx950) need no canonicalising copies
+// of their inputs and propagate a NaN — which only ever comes with a NaN error bound and sends the pair to the exact pass.
+__device__ __forceinline__ float fmin_raw(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+__device__ __forceinline__ float fmax_raw(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float fmed3_raw(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+__device__ __forceinline__ float fmin3_raw(float a, float b, float c) { return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c); }
 constexpr int kQueueCap = 1024;  // undecided pairs a workgroup can defer to its exact pass (4 KB of LDS)
 
 // exact float64 nearest-of-K of one (source point, particle) pair, candidate-parallel over G lanes (lane id `sub` in
@@ -177,6 +180,23 @@ constexpr float kEpsBf16 = (float)SVNICP_SEARCH_EPS_U * 5.9604644775390625e-08f;
 // Work split: all four waves of a workgroup walk source points (one point per wave step when PW = 64); a wave handles
 // ALL WP groups of PW particles of its points one after the other, so a point's table rows are fetched and split into
 // bf16 pieces once for the whole workgroup's particles.
+//
+// Tracking by TILES (round 3, second half).  A result register quad of one MFMA holds four CONSECUTIVE candidates
+// (16·rb + 4·mk + 0..3) of one particle: a tile.  Keeping the smallest and second smallest of all 24 scores of a lane cost
+// 32 slow-class + 24 tag instructions per column block — measured (timing-only builds): the second minimum alone was 31 % of
+// the kernel, the per-score tags 11 %.  Now a lane keeps the minimum of each tile (v_min3 + v_min), tags the six TILE minima
+// (3 bits row block, 2 bits lane group) and tracks the smallest and second smallest tile minimum: 19 slow + 6 tags per column
+// block.  That decides between tiles; inside the winning tile the lane that owns the particle scores the four candidates
+// itself, one step later, from an array-of-rows copy of the table (tablef: 64 contiguous bytes per lane, requested at the end
+// of the step, consumed after the next step's transform), in float32 FMAs on the same inputs:
+//   (a) inside the tile: packed VALU scores v1 < v2 (2 tag bits, 3 ulp) with v2 − v1 > 2·EPS + 2^-21(|v1| + |v2|): each
+//       VALU score is within EPS of the exact score (inputs (i), three roundings <= 3.01u·Σ|products|, (iv)), so the tile's
+//       other three candidates are strictly farther in exact arithmetic than the VALU argmin t*;
+//   (b) other tiles: with b1 < b2 the smallest and second smallest TAGGED tile minima (5 tag bits: < 2^-18 relative),
+//       b2 − b1 > 2·EPS + 2^-18(|b1| + |b2|): every candidate j outside the winning tile has exact score
+//       s_j >= b2 − 2^-18|b2| − EPS, and the winning tile's matrix-pipe argmin j* has s_j* <= b1 + 2^-18|b1| + EPS; by (a)
+//       s_t* <= s_j*, so s_t* < s_j.
+// (a) and (b) and t* < K: t* is the float64 argmin with no tie; anything else goes to the exact pass as before.
 template <int PW, int WP, int NRB, bool TAIL>
 #ifndef SVNICP_SEARCH_WAVES
 #define SVNICP_SEARCH_WAVES 4
@@ -188,6 +208,8 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
   constexpr int NPT = 4 / CBP;     // distinct source points per wave step
   constexpr int ST = 4 * BW;       // source points between two steps of a wave (four waves along the points)
   constexpr bool PIPE = NPT == 1;  // one point per step: its table rows are fetched a step ahead
+  constexpr int NTILE = 4 * NRB + (TAIL ? 1 : 0);   // tiles of four consecutive candidates per source point
+  __shared__ float4 s_rows[4][NPT][4][NTILE];   // per wave and point: row k = (c'x, c'y, c'z, |c'|²) at [k & 3][k >> 2]
   __shared__ float4 s_scr4[4][64];       // per wave: (−2x', 1) of each particle lane of the group in flight
   __shared__ double s_pose[WP][12][64];  // the lanes' total poses, re-read every step: 24 VGPRs less than keeping them
   __shared__ unsigned int s_queue[kQueueCap];   // undecided pairs: (point − blk_lo) << 8 | particle lane of the workgroup
@@ -213,6 +235,10 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
   const SVNICP_CONST_AS float* ccmax = (const SVNICP_CONST_AS float*)a.cmax;
   const SVNICP_CONST_AS v4f* ctail = (const SVNICP_CONST_AS v4f*)a.tail;
   const SVNICP_CONST_AS v4f* ctab = (const SVNICP_CONST_AS v4f*)a.tablea;
+  const v4f* gtail = reinterpret_cast<const v4f*>(a.tail);
+  // LDS copy of a point's rows, written from the A-operand registers: lane (mj, mk) holds component mk of candidates
+  // 16·rb + mj — one 4-byte store per row block
+  float* const rows_w = reinterpret_cast<float*>(&s_rows[wave][0][mj & 3][mj >> 2]) + mk;
   const int64_t blk_lo = (int64_t)blockIdx.x * a.spts_per_block;
   const int64_t blk_hi = (blk_lo + a.spts_per_block < a.B) ? blk_lo + a.spts_per_block : a.B;
   __syncthreads();
@@ -221,12 +247,13 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
   int pend_idx = 0;       // winner's target index of the previous step, stored one step late (see the end of the step)
   size_t pend_off = 0;
   bool pend_have = false;
-  v4f alo_n, ahi_n;   // PIPE: table rows of the NEXT step, in flight while this step's tiles run
+  v4f alo_n, ahi_n, tl_n = {0.f, 0.f, 0.f, 0.f};   // PIPE: table rows of the NEXT step, in flight while this step's tiles run
   if constexpr (PIPE) {
     const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)(nfirst < blk_hi ? nfirst : blk_lo) * 128 + lane;
     alo_n = rowp[0];
     ahi_n = alo_n;
     if constexpr (NRB > 4) ahi_n = rowp[64];
+    if constexpr (TAIL) tl_n = gtail[(size_t)(nfirst < blk_hi ? nfirst : blk_lo) * 4 + (lane & 3)];
   }
 
   for (int64_t n = nfirst; n < blk_hi; n += ST) {  // wave-uniform
@@ -243,27 +270,32 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
     // used by every particle group; several points per step (PW < 64, one particle group): split when the column blocks reach
     // the point
     bf8 afr[NRB];
-    auto split_rows = [&](v4f alo, v4f ahi) {
+    auto split_rows = [&](v4f alo, v4f ahi, int pt) {   // pt: which of the step's NPT points
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) {
         const float v = rb == 0 ? alo.x : rb == 1 ? alo.y : rb == 2 ? alo.z : rb == 3 ? alo.w
                       : rb == 4 ? ahi.x : rb == 5 ? ahi.y : rb == 6 ? ahi.z : ahi.w;
         afr[rb] = split_a3(v);
+        rows_w[(pt * 4 * NTILE + 4 * rb) * 4] = v;   // row 16·rb + mj lives at [(mj & 3)][4·rb + (mj >> 2)]
       }
     };
     if constexpr (PIPE) {
       const v4f alo = alo_n, ahi = ahi_n;
+      const v4f tlc = tl_n;
       int64_t nn = n + ST;
       nn = nn < blk_hi ? nn : n;
       const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)nn * 128 + lane;
       alo_n = rowp[0];
       if constexpr (NRB > 4) ahi_n = rowp[64];
-      split_rows(alo, ahi);
+      if constexpr (TAIL) tl_n = gtail[(size_t)nn * 4 + (lane & 3)];
+      __builtin_amdgcn_wave_barrier();   // the previous step's tile reads are done
+      split_rows(alo, ahi, 0);
+      if constexpr (TAIL) { if (lane < 4) *reinterpret_cast<v4f*>(&s_rows[wave][0][lane][4 * NRB]) = tlc; }   // rows 16·NRB + lane
     }
 
 #pragma nounroll
     for (int g = 0; g < WP; ++g) {   // not unrolled: the groups would only compete for registers
-      float E;
+      float E, mm0, mm1, mm2;
       {
         const double (*pose)[64] = s_pose[g];
         const double T0 = (s0 * pose[0][lane] + s1 * pose[1][lane] + s2 * pose[2][lane]) + pose[9][lane];   // SVNICP.cpp:62-64
@@ -274,8 +306,9 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
         const float X2 = __builtin_amdgcn_sqrtf(__builtin_fmaf(xf0, xf0, __builtin_fmaf(xf1, xf1, xf2 * xf2))) * 1.000002f;
         const float Cq = __builtin_fmaf(5.9604644775390625e-08f, X2, C);   // NaN (a sentinel row, a non-finite point) stays NaN
         E = kEpsBf16 * Cq * __builtin_fmaf(2.0f, X2, Cq);
+        mm0 = -2.0f * xf0; mm1 = -2.0f * xf1; mm2 = -2.0f * xf2;
         if (g > 0) __builtin_amdgcn_wave_barrier();      // the previous group's readers are done with the scratch
-        s_scr4[wave][lane] = make_float4(-2.0f * xf0, -2.0f * xf1, -2.0f * xf2, 1.0f);
+        s_scr4[wave][lane] = make_float4(mm0, mm1, mm2, 1.0f);
         __builtin_amdgcn_wave_barrier();
       }
       const float* scr4f = reinterpret_cast<const float*>(s_scr4[wave]);
@@ -283,6 +316,7 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
       float braw[4];
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) braw[cb] = scr4f[(16 * cb + mj) * 4 + mk];
+
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
         if constexpr (!PIPE) {
@@ -293,17 +327,17 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
             const v4f alo = rowp[0];
             v4f ahi = alo;
             if constexpr (NRB > 4) ahi = rowp[64];
-            split_rows(alo, ahi);
+            split_rows(alo, ahi, cb / CBP);
+            if constexpr (TAIL) { if (lane < 4) *reinterpret_cast<v4f*>(&s_rows[wave][cb / CBP][lane][4 * NRB]) = gtail[(size_t)bq * 4 + lane]; }
           }
         }
         const bf8 bfr = split_b3(braw[cb]);
         const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
-        // smallest and second smallest of the lane's 4*NRB packed scores.  Three scores give a (smallest, second) pair in
-        // two instructions (v_min3, v_med3); two such pairs are folded into the running pair in four (the second smallest
-        // of three pairs is min(med3 of the three smallest, the three seconds)): 8 instructions per 6 scores, where the
-        // one-at-a-time update (v_med3 + v_min per score) took 12 — these are the slow-issue instruction class.
+        // smallest and second smallest of the lane's NRB tagged TILE minima.  Three values give a (smallest, second) pair
+        // in two instructions (v_min3, v_med3); two such pairs are folded into the running pair (the second smallest of
+        // three pairs is min(med3 of the three smallest, the three seconds)) — these are the slow-issue instruction class.
         float m1 = 0.0f, m2 = 0.0f, wp = 0.0f, rp = 0.0f, pend0 = 0.0f, pend1 = 0.0f;
-        int np = 0;            // scores waiting for a triple            (all three: compile-time after unrolling)
+        int np = 0;            // tile minima waiting for a triple      (all three: compile-time after unrolling)
         bool have_m = false;   // (m1, m2) hold a pair
         bool have_p = false;   // (wp, rp) hold a pair waiting for its partner
         v4f dcur = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0], bfr, zero, 0, 0, 0);
@@ -311,32 +345,29 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
         for (int rb = 0; rb < NRB; ++rb) {  // tile rb+1 goes to the matrix pipe before the VALU consumes tile rb
           v4f dnext = dcur;
           if (rb + 1 < NRB) dnext = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[rb + 1], bfr, zero, 0, 0, 0);
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const float pk = pack_slot3(dcur[v], (unsigned int)(rb * 4 + v));
-            if (np == 0) { pend0 = pk; np = 1; }
-            else if (np == 1) { pend1 = pk; np = 2; }
+          const float pk = pack_slot3(fmin_raw(fmin3_raw(dcur[0], dcur[1], dcur[2]), dcur[3]), (unsigned int)rb);
+          if (np == 0) { pend0 = pk; np = 1; }
+          else if (np == 1) { pend1 = pk; np = 2; }
+          else {
+            np = 0;
+            const float w = fmin3_raw(pend0, pend1, pk), r = fmed3_raw(pend0, pend1, pk);
+            if (!have_p) { wp = w; rp = r; have_p = true; }
             else {
-              np = 0;
-              const float w = fmin3_raw(pend0, pend1, pk), r = fmed3_raw(pend0, pend1, pk);
-              if (!have_p) { wp = w; rp = r; have_p = true; }
-              else {
-                have_p = false;
-                if (!have_m) {      // first two triples: a plain merge of two pairs
-                  m1 = fmin_raw(wp, w);
-                  m2 = fmin3_raw(fmax_raw(wp, w), rp, r);
-                  have_m = true;
-                } else {
-                  const float md = fmed3_raw(m1, wp, w);
-                  m2 = fmin_raw(fmin3_raw(m2, rp, r), md);
-                  m1 = fmin3_raw(m1, wp, w);
-                }
+              have_p = false;
+              if (!have_m) {      // first two triples: a plain merge of two pairs
+                m1 = fmin_raw(wp, w);
+                m2 = fmin3_raw(fmax_raw(wp, w), rp, r);
+                have_m = true;
+              } else {
+                const float md = fmed3_raw(m1, wp, w);
+                m2 = fmin_raw(fmin3_raw(m2, rp, r), md);
+                m1 = fmin3_raw(m1, wp, w);
               }
             }
           }
           dcur = dnext;
         }
-        // what is left over when 4*NRB is not a multiple of six
+        // what is left over when NRB is not a multiple of six
         if (!have_m) { m1 = __builtin_huge_valf(); m2 = __builtin_huge_valf(); }
         if (have_p) { const float t = fmax_raw(m1, wp); m1 = fmin_raw(m1, wp); m2 = fmin3_raw(t, m2, rp); }
         if (np >= 1) { m2 = fmed3_raw(m1, m2, pend0); m1 = fmin_raw(m1, pend0); }
@@ -348,7 +379,7 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
       // its own entry and its row partner's; after v_permlane32_swap on those two results lane group mk holds both halves of
       // column block mk.  Six swaps, no copies, no selects; the result lands in the lane that owns the particle.
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) b1[cb] = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(b1[cb]), 0x60u, (unsigned int)mk << 5, 0xBA));
+      for (int cb = 0; cb < 4; ++cb) b1[cb] = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(b1[cb]), 0x18u, (unsigned int)mk << 3, 0xBA));
       auto merge2 = [&](float p1, float q1, float p2, float q2, float& o1, float& o2) {
         o1 = fmin_raw(p1, q1);
         o2 = fmin_raw(fmax_raw(p1, q1), fmin_raw(p2, q2));
@@ -366,25 +397,43 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
         const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h2[0]), __float_as_uint(h2[1]), false, false);
         merge2(__uint_as_float(r1[0]), __uint_as_float(r1[1]), __uint_as_float(r2[0]), __uint_as_float(r2[1]), b1own, b2own);
       }
-      if constexpr (TAIL) {
+      if constexpr (TAIL) {   // candidates 16·NRB … +3: one more tile (row block NRB of lane group 0), scored by the owner lane
         const SVNICP_CONST_AS v4f* tl = ctail + (size_t)bl * 4;
-        const float4 mm = s_scr4[wave][lane];   // (−2x', 1) of this lane's own particle
+        float sc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const v4f c = tl[t];  // (c'x, c'y, c'z, |c'|²), a finite sentinel past K
-          const float sc = __builtin_fmaf(c.x, mm.x, __builtin_fmaf(c.y, mm.y, __builtin_fmaf(c.z, mm.z, c.w)));
-          const float pk = pack_slot(sc, 0x7fu, (unsigned int)(NRB * 4 + t));  // slot of candidate 16·NRB + t, lane group 0
-          b2own = fmed3_raw(b1own, b2own, pk);
-          b1own = fmin_raw(b1own, pk);
+          sc[t] = __builtin_fmaf(c.x, mm0, __builtin_fmaf(c.y, mm1, __builtin_fmaf(c.z, mm2, c.w)));
         }
+        const float pk = pack_slot(fmin_raw(fmin3_raw(sc[0], sc[1], sc[2]), sc[3]), 0x1fu, (unsigned int)NRB);
+        b2own = fmed3_raw(b1own, b2own, pk);
+        b1own = fmin_raw(b1own, pk);
       }
 
       const int pin = g * PW + pl;                        // particle lane inside the workgroup
       const bool valid = inb && (a.p_lo + pbase + pin) < a.p_hi;
       const unsigned int wbits = __float_as_uint(b1own);
-      int kb = (int)(((wbits & 0x1cu) << 2) | ((wbits >> 3) & 0xcu) | (wbits & 3u));  // 16·rb + 4·mk + v
-      const float thr = 2.0f * E + 1.5318394e-05f * (__builtin_fabsf(b1own) + __builtin_fabsf(b2own)) + 1.0e-30f;   // 2^-16·(1 + 2^-8)
-      const bool ambiguous = valid && (!(b2own - b1own > thr) || kb >= K);
+      int tile = (int)(((wbits & 7u) << 2) | ((wbits >> 3) & 3u));    // 4·rb + mk: candidates 4·tile … 4·tile + 3
+      tile = tile < NTILE ? tile : NTILE - 1;                         // (a NaN's tag bits are anything: stay inside the rows)
+      const float thr = 2.0f * E + 3.83e-06f * (__builtin_fabsf(b1own) + __builtin_fabsf(b2own)) + 1.0e-30f;   // 2^-18 and a little
+      const bool tiles_ok = b2own - b1own > thr;
+      // inside the winning tile: the four candidates scored by this lane from the LDS rows, tagged with two bits
+      float pk4[4];
+      {
+        const float4* rt = &s_rows[wave][bs][0][tile];
+        if constexpr (!PIPE) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float4 r = rt[t * NTILE];
+          const float sc = __builtin_fmaf(r.x, mm0, __builtin_fmaf(r.y, mm1, __builtin_fmaf(r.z, mm2, r.w)));
+          pk4[t] = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(sc), 3u, (unsigned int)t, 0xBA));
+        }
+      }
+      const float w3 = fmin3_raw(pk4[0], pk4[1], pk4[2]), r3 = fmed3_raw(pk4[0], pk4[1], pk4[2]);
+      const float v1 = fmin_raw(w3, pk4[3]), v2 = fmed3_raw(w3, r3, pk4[3]);
+      const float thrv = 2.0f * E + 4.76837158203125e-07f * (__builtin_fabsf(v1) + __builtin_fabsf(v2)) + 1.0e-30f;   // 2^-21
+      int kb = 4 * tile + (int)(__float_as_uint(v1) & 3u);
+      const bool ambiguous = valid && (!tiles_ok || !(v2 - v1 > thrv) || kb >= K);
       kb = kb < K ? kb : 0;
       unsigned long long am = __ballot(ambiguous);
       if (am) {  // rare (about one wave step in ten, a lane or two each): queue the undecided pairs for the exact pass below
@@ -623,7 +672,7 @@ __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulat
 // candidate table of the search kernel: one wave per source point.  Candidates relative to the point's first candidate as
 // float32 (c'x, c'y, c'z, |c'|²) in MFMA A-operand order (lane = 16·component + candidate mod 16, one float4 per four 16-row
 // blocks; rows past K are finite sentinels), the origin of the local frame, C_b = max |c'|₂ rounded up (the error bound's
-// C2) and candidates 96…99 for the owner-lane tail.  Replaces the I copies of target_batch [B,K,3] of SVGDICP.cpp:191-198.
+// C2) and candidates 96…99 (the tile the owner lanes score themselves when K is 97…100).  Replaces the I copies of target_batch [B,K,3] of SVGDICP.cpp:191-198.
 // ---------------------------------------------------------------------------------------------
 constexpr float kSentinelCC = 1.0e30f; // padded rows: finite, so packed words never become NaN patterns
 __global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict__ idx, int64_t B, int K,

@@ -408,7 +408,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   auto num = [&](int lo, int hi, int* out) { char* end = nullptr; const long x = strtol(v.c_str(), &end, 10);
                                              if (end == v.c_str() || *end || x < lo || x > hi) return false; *out = (int)x; return true; };
   bool ok = true;
-  if (k == "knn") { if (v == "auto") t.knn = -1; else if (v == "v1") t.knn = 0; else if (v == "v2") t.knn = 1; else ok = false; }
+  if (k == "knn") { if (v == "auto") t.knn = -1; else if (v == "v1") t.knn = 0; else if (v == "v2") t.knn = 1; else if (v == "brute") t.knn = 2; else if (v == "tiles") t.knn = 3; else ok = false; }
   else if (k == "fallback_sliced_max") ok = num(-1, 1 << 20, &t.fallback_sliced_max);
   else if (k == "accum") { if (v == "f64") t.accum = 0; else if (v == "valu") t.accum = 1; else if (v == "split") t.accum = 3; else ok = false; }
   else if (k == "update") { if (v == "auto") t.update_fused = 0; else if (v == "fused") t.update_fused = 1; else ok = false; }
@@ -458,10 +458,13 @@ static int ensure_target_layout(svnicp_ctx* c) {
   int want = 0;
   if (knn_tiles_applicable(c->Mp, c->K)) want = 2;
   else if (knn_scan_plan(c->Mp, c->K, &c->scan_Ms, &c->scan_rank, &c->scan_S2)) want = 1;
-  if (c->tune.knn == 0) want = 0;   // option "knn": v1 | v2 (A/B for tests and profiling)
+  if (c->tune.knn == 0) want = 0;   // option "knn": v1 | v2 | brute | tiles (A/B for tests and profiling)
   if (c->tune.knn == 1) want = knn_scan_plan(c->Mp, c->K, &c->scan_Ms, &c->scan_rank, &c->scan_S2) ? 1 : 0;
+  // small registrations (the scan-to-map loop's sizes, BASELINE C1): brute force in one launch, no target layout at all
+  if ((c->tune.knn == -1 && knn_brute_applicable(c->B, c->M, c->K)) || (c->tune.knn == 2 && c->K <= 128 && c->M < (1ll << 31))) want = 3;
   c->knn_variant = want;
   c->use_scan = want == 1;
+  if (want == 3) return 0;
   const int layout = want == 2 ? 1 : 0;
   if (c->target_layout == layout) return 0;
   const int64_t M = c->M, Mp = c->Mp;
@@ -500,7 +503,9 @@ int svnicp_align_begin(svnicp_ctx* c) {
   c->S = knn_pool_size(c->K);
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (ensure_target_layout(c)) return c->err.empty() ? SVNICP_ERR_HIP : SVNICP_ERR_HIP;
-  if (c->knn_variant != 0) {
+  if (c->knn_variant == 3) {
+    HIPCHK(c, c->fail_count.ensure(1));   // svnicp_get_knn_fallbacks: the brute-force kernel has none (cleared by the begin kernel below)
+  } else if (c->knn_variant != 0) {
     if (c->knn_variant == 2) {
       // survivors of the f32 pre-filter: 512 slots per query (median 127 at C3) + a shared arena of 512-slot chunks for the
       // heavy tail (C3: 0.4 % of the queries, 0.17 M entries; C5: 4 %, 3.1 M entries, up to 9016 per query)
@@ -532,8 +537,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
   HIPCHK(c, c->cand_d2.ensure((size_t)B * c->K));
   c->accum_mode = c->tune.accum;   // option "accum": f64 | valu | split
   HIPCHK(c, c->cmaxb.ensure((size_t)B));
-  HIPCHK(c, c->ambig.ensure(2));   // [0] wave steps with an undecided lane, [1] undecided (point, particle) pairs
-  HIPCHK(c, hipMemsetAsync(c->ambig.p, 0, 2 * sizeof(int), c->stream));
+  HIPCHK(c, c->ambig.ensure(2));   // [0] wave steps with an undecided lane, [1] undecided (point, particle) pairs (cleared by the begin kernel below)
   HIPCHK(c, c->history.ensure((size_t)(I > 0 ? I : 1) * 6 * P));
   c->hist_I = I; c->hist_P = P;
   const int nshard = c->p_hi - c->p_lo;
@@ -546,7 +550,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
     if (c->plan.smem > 160u * 1024)   // K > 128 runs the LDS-tile VALU search: its smallest tile must fit one CU's LDS
       return fail(c, SVNICP_ERR_INVALID, "svnicp_align: knn_count " + std::to_string(c->K) + " needs " + std::to_string(c->plan.smem) +
                   " bytes of LDS per workgroup (limit 163840): the candidate count is too large for this particle count");
-    HIPCHK(c, c->partial.ensure((size_t)c->plan.grid_x * c->plan.Ppad * kNSums));
+    HIPCHK(c, c->partial.ensure((size_t)std::max(c->plan.grid_x, P == 1 ? single_particle_grid(B) : 0) * c->plan.Ppad * kNSums));
   } else {
     c->plan = AccumPlan{};
     c->plan.f32 = c->accum_mode == 3 ? 1 : c->accum_mode;
@@ -573,7 +577,6 @@ int svnicp_align_begin(svnicp_ctx* c) {
   c->single_done_it = -1;
   if (c->median_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // a registration that was abandoned between its two per-iteration calls
   c->median_pending = false;
-  HIPCHK(c, hipMemsetAsync(c->uctl.p, 0, update_uctl_doubles(P) * sizeof(double), c->stream));   // tickets, counters, pair histogram
   if (!c->finish_seen && c->prm.mode == SVNICP_MODE_SVGD && c->prm.check_early_stop) {
     // finish_iter_ is sticky across registrations (SVGDICP.cpp:42,128): fold the previous registration's stop flag in before
     // the control words are reset, in case nobody asked for svnicp_get_runtime in between (SVGD mode with early stop only)
@@ -583,14 +586,22 @@ int svnicp_align_begin(svnicp_ctx* c) {
     if (v[0]) c->finish_iter = v[1];
     c->finish_seen = true;
   }
-  const int ctl_init[4] = {0, I, 0, 0};  // stop flag, finish_iter (SVGDICP.cpp:42)
-  HIPCHK(c, hipMemcpyAsync(c->ctl.p, ctl_init, sizeof ctl_init, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->history.p, 0, (size_t)(I > 0 ? I : 1) * 6 * P * sizeof(float), c->stream));  // SVGDICP.cpp:172-174
-  // total pose of iteration 0 from the CURRENT R_, t_ and R0, t0 (SVNICP.cpp:58-59)
-  HIPCHK(c, launch_init_particles(c->init_pose.p, P, c->pose0, 2, c->R.p, c->t.p, c->Rtot.p, c->pose_out.p, 0,
-                                  nullptr, c->stream));
-  if (c->prm.mode == SVNICP_MODE_SVGD)  // a fresh torch::optim optimizer per stein_align (SVGDICP.cpp:73,142-170)
-    HIPCHK(c, hipMemsetAsync(c->opt.p, 0, (size_t)P * 18 * sizeof(double), c->stream));
+  // ONE launch for everything small that a registration starts from: control words {stop flag, finish_iter (SVGDICP.cpp:42)},
+  // tickets / counters / pair histogram, the float32 history (SVGDICP.cpp:172-174), statistics counters, a fresh optimizer
+  // state (SVGDICP.cpp:73,142-170) — and the total pose of iteration 0 from the CURRENT R_, t_ and R0, t0 (SVNICP.cpp:58-59).
+  // (Five fill / copy launches before: 5-8 us each, a tenth of a scan-to-map registration.)
+  {
+    BeginZero z{};
+    auto add = [&](void* p, size_t bytes) { if (p && bytes) { z.ptr[z.n] = static_cast<unsigned int*>(p); z.dwords[z.n] = (unsigned int)(bytes / 4); ++z.n; } };
+    add(c->uctl.p, update_uctl_doubles(P) * sizeof(double));
+    add(c->history.p, (size_t)(I > 0 ? I : 1) * 6 * P * sizeof(float));
+    add(c->ambig.p, 2 * sizeof(int));
+    if (c->knn_variant == 3) add(c->fail_count.p, sizeof(int));
+    if (c->prm.mode == SVNICP_MODE_SVGD) add(c->opt.p, (size_t)P * 18 * sizeof(double));
+    z.ctl = c->ctl.p; z.iterations = I;
+    HIPCHK(c, launch_init_particles(c->init_pose.p, P, c->pose0, 2, c->R.p, c->t.p, c->Rtot.p, c->pose_out.p, 0,
+                                    nullptr, c->stream, &z));
+  }
   c->particles_dirty = false;
   c->began = true;
   c->finish_seen = false;
@@ -623,7 +634,24 @@ static int stage_a(svnicp_ctx* c, const double* qsrc, const Pose0& pose, int K, 
   a.src = qsrc; a.pose = pose; a.tx = c->tx.p; a.ty = c->ty.p; a.tz = c->tz.p; a.torig = c->torig.p;
   a.M = c->M; a.Mp = c->Mp; a.b_lo = b_lo; a.b_hi = b_hi; a.K = K; a.S = knn_pool_size(K);
   a.pool_d = c->pool_d.p; a.pool_i = c->pool_i.p; a.out_idx = out_idx; a.out_d2 = out_d2;
-  if (c->knn_variant == 2) {
+  if (c->knn_variant == 3) {
+    KnnBruteArgs k{};
+    k.src = qsrc; k.pose = pose; k.tgt = c->tgt.p; k.M = c->M; k.b_lo = b_lo; k.b_hi = b_hi; k.K = K; k.out_idx = out_idx; k.out_d2 = out_d2;
+    if (c->tune.debug) {
+      if (!c->dbg_phase) HIPCHK(c, hipMalloc(&c->dbg_phase, (8 + 8 * 65536) * sizeof(unsigned long long)));
+      HIPCHK(c, hipMemsetAsync(c->dbg_phase, 0, 8 * sizeof(unsigned long long), c->stream));
+      k.phase_cycles = c->dbg_phase;
+    }
+    HIPCHK(c, launch_knn_brute(k, c->stream));
+    if (k.phase_cycles) {
+      unsigned long long h[8];
+      HIPCHK(c, hipMemcpyAsync(h, c->dbg_phase, sizeof h, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const double nwg = (double)((b_hi - b_lo + 3) / 4);
+      fprintf(stderr, "[svnicp] k_knn_brute thread-0 cycles per workgroup: pass A %.0f, bound %.0f, pass B %.0f, general path %.0f, rank + write %.0f\n",
+              h[0] / nwg, h[1] / nwg, h[2] / nwg, h[3] / nwg, h[4] / nwg);
+    }
+  } else if (c->knn_variant == 2) {
     const int64_t n = b_hi - b_lo;
     if (n > 0) {
       HIPCHK(c, launch_morton_order(qsrc, b_lo, n, 1, pose, c->bbox.p, c->keys_a.p, c->keys_b.p, c->vals_a.p,
@@ -701,7 +729,7 @@ int svnicp_stage_candidates(svnicp_ctx* c, int64_t b_lo, int64_t b_hi) {
   HIPCHK(c, prof_begin(c, KC_KNN));
   const int rc = stage_a(c, c->src.p, c->pose0, c->K, c->cand_idx.p, c->cand_d2.p, b_lo, b_hi);
   if (rc) return rc;
-  if (c->tune.full_corr && c->knn_variant != 0) {   // svnicp_get_knn_fallbacks / _rows describe STAGE A, not the last particle's K = 1 search
+  if (c->tune.full_corr && c->knn_variant != 0 && c->knn_variant != 3) {   // svnicp_get_knn_fallbacks / _rows describe STAGE A, not the last particle's K = 1 search
     HIPCHK(c, c->stage_fail_count.ensure(1)); HIPCHK(c, c->stage_fail_list.ensure((size_t)c->B));
     HIPCHK(c, hipMemcpyAsync(c->stage_fail_count.p, c->fail_count.p, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->stage_fail_list.p, c->fail_list.p, (size_t)c->B * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));

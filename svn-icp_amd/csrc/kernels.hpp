@@ -34,6 +34,21 @@ int knn_slice_count(int K);
 hipError_t launch_knn_merge_slices(const KnnArgs& a, hipStream_t st);
 int64_t knn_padded_targets(int64_t M);
 
+// ---------------- Stage A for small registrations (knn_brute.hip) ----------------
+struct KnnBruteArgs {
+  const double* src;   // [B][3] source cloud (un-transformed)
+  Pose0 pose;          // R0, t0
+  const double* tgt;   // [M][3] target cloud as given (no re-ordered copy)
+  int64_t M;
+  int64_t b_lo, b_hi;  // query rows of this launch
+  int K;
+  int32_t* out_idx;    // [B][K]
+  double* out_d2;      // [B][K]
+  unsigned long long* phase_cycles;   // optional [8]: thread-0 cycles per phase, summed over the workgroups (option debug)
+};
+bool knn_brute_applicable(int64_t B, int64_t M, int K);
+hipError_t launch_knn_brute(const KnnBruteArgs& a, hipStream_t st);
+
 // ---------------- Stage A fast variant (knn_scan.hip) ----------------
 struct KnnScanArgs {
   const double* src;
@@ -142,7 +157,7 @@ struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f3
 // accumulation kernel (falls back to 1 when K > 128 or the shard has <= 8 particles)
 // test / profiling knobs of a context (svnicp_set_option); the defaults are the product configuration
 struct Tuning {
-  int knn = -1;                  // stage A kernel: -1 automatic, 0 streaming only (v1), 1 seeded scan (v2)
+  int knn = -1;                  // stage A kernel: -1 automatic, 0 streaming only (v1), 1 seeded scan (v2), 2 brute force (small sizes), 3 Morton tiles even where brute force applies
   int fallback_sliced_max = -1;  // stage A: failed queries redone by target slices up to this many (-1 default)
   int accum = 3;                 // stage B: 0 f64 baseline, 1 f32 VALU search (fused), 3 search + accumulate kernels
   int update_fused = 0;          // Stein update: 1 = one fused kernel for 2 <= P <= fused_update_max_p
@@ -194,10 +209,13 @@ struct UpdateArgs {
   unsigned long long* dbg;  // optional [8]: cycle stamps of the fused kernel's phases (SVNICP_DEBUG)
 };
 size_t update_workspace_doubles(int P);
+// areas k_init_particles clears at the start of a registration (whole 32-bit words), and the control words it resets
+struct BeginZero { unsigned int* ptr[6]; unsigned int dwords[6]; int n; int* ctl; int iterations; };
 hipError_t launch_init_particles(const double* init6xP, int P, const Pose0& pose, int mode, double* R, double* t,
-                                 double* Rtot, double* pose_out, int refresh_pose, double* eul, hipStream_t st);
+                                 double* Rtot, double* pose_out, int refresh_pose, double* eul, hipStream_t st, const BeginZero* zero = nullptr);
 // stage B accumulate (fused variants: whole stage B); single: see stein_iter.hip — the one-particle iteration in one launch
 bool accumulate_can_fuse_single(const AccumPlan& plan);
+int single_particle_grid(int64_t B);   // workgroups of the one-particle iteration kernel (rows of `partial` it writes)
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, const UpdateArgs* single, hipStream_t st);
 hipError_t launch_update_svgd(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);

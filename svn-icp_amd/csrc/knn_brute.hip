@@ -1,0 +1,383 @@
+// knn_brute.hip — Stage A for SMALL registrations: exact top-K by brute force, one launch, no target layout.
+//
+// The scan-to-map loop hands the solver ~1 000 source points against a ~50 000-point local map
+// (OdometryPipeline.cpp:559-560; shipped config/*.yaml), BASELINE C1 is 4 096 x 8 192.  At these sizes the Morton-tile
+// path is all fixed cost: bounding box, two radix sorts, the re-ordered target copies, three kernels whose grids do not
+// fill the chip (k_knn_seed: 18 workgroups for 1 113 queries, 140 us) and three fallback launches — 0.26–0.44 ms for
+// 3e7–6e7 point pairs.  k_knn_brute evaluates every pair in float64 with the reference's arithmetic (SVGDICP.cpp:201-215,
+// knn_cpu.cpp:35-67: q = (s·R0ᵀ) + t0, d² = ((dx·dx)+dy·dy)+dz·dz unfused) and selects by radix on the bit pattern of d²
+// (non-negative doubles order like unsigned integers):
+//   a workgroup = 4 queries x all targets (1024 threads, thread <-> every 1024th target, AoS rows as given: no copy of the cloud);
+//   pass A   every thread keeps the minimum d² of ITS targets: 1024 values from 1024 distinct targets per query, so their
+//            K-th smallest (bisection on the bit patterns, one wave per query) is a bound that at least K targets meet —
+//            and a tight one: the K nearest targets mostly fall to different threads (the trick of k_knn_seed);
+//   pass B   the targets within the bound (typically 1.2–2 K of them) are collected into an LDS pool of 256 entries,
+//            ranked by counting under (d², original index) and the first K written in ascending order — the contract of
+//            every stage-A kernel here (ties by lowest index, zero padding when fewer than K targets exist, NaN
+//            distances never selected).
+// A query whose bound admits more than 256 targets (dense duplicates, exact ties) takes the general path instead: a
+// histogram of a 10-bit key of d² (exponent + 3 mantissa bits, window 2^-64 … 2^64) under the bound, and if the bins up to
+// the K-th still hold more than 256 targets, radix select over the full 64 bits of d², 10 bits per pass, then over the 32
+// bits of the index for exact ties — always terminates with at most 256 collected targets, so this kernel has no
+// fallback launches.
+#include "kernels.hpp"
+
+namespace svnicp {
+
+namespace {
+
+constexpr int kQB = 4;          // queries per workgroup = waves per workgroup (wave q analyses query q's histogram)
+constexpr int kCap = 256;       // pool entries per query (one entry per thread of the query's quarter of the workgroup in the ranking)
+constexpr int kNTB = 1024;      // threads per workgroup: 16 waves, four per SIMD — the sweeps are f64 dependency chains, occupancy hides them
+constexpr int kBins = 1024;
+constexpr int kWinBase = (1023 - 64) << 3;   // key 0 <-> d² < 2^-64 (incl. 0), key 1023 <-> d² >= 2^64 (incl. +inf)
+
+// per-query selection state (LDS)
+enum : int { M_WINDOW = 0, M_DBITS = 1, M_INDEX = 2, R_WINDOW = 3, R_DBITS = 4, R_INDEX = 5, R_ALL = 6, R_DONE = 7 };   // R_DONE: settled by passes A and B
+struct QState {
+  int mode;
+  int m, mi;                 // matched high bits of d² / of the index
+  int below;                 // targets known to lie below the current prefix
+  int b0;                    // R_WINDOW: collect keys <= b0
+  int filter;                // M_WINDOW: count keys <= filter only
+  unsigned int ipfx;
+  unsigned long long pfx;
+};
+
+__device__ __forceinline__ int win_key(unsigned long long bits) {
+  int d = (int)(bits >> 49) - kWinBase;
+  d = d < 0 ? 0 : d;
+  return d > kBins - 1 ? kBins - 1 : d;
+}
+
+template <bool COLLECT>
+__device__ __forceinline__ void brute_pass(const KnnBruteArgs& a, const double (&qx)[kQB], const double (&qy)[kQB], const double (&qz)[kQB],
+                                           int nq, const QState* st, unsigned int (*hist)[kBins], double (*pd)[kCap], int (*pi)[kCap],
+                                           unsigned int* pn, int64_t j0, int64_t stride, int64_t n_steps, bool only_window) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  QState s[kQB];
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) s[q] = st[q];   // wave-uniform
+  for (int64_t it = 0; it < n_steps; ++it) {   // workgroup-uniform trip count
+    const int64_t j = (j0 + it * kNTB + tid) * stride;
+    const bool in = j < a.M;
+    const double* tp = a.tgt + 3 * (in ? j : 0);
+    const double tx = tp[0], ty = tp[1], tz = tp[2];
+    const unsigned int idx = (unsigned int)j;
+#pragma unroll
+    for (int q = 0; q < kQB; ++q) {
+      if (q >= nq) break;
+      const int mode = s[q].mode;
+      if (!COLLECT && (mode >= R_WINDOW || (only_window && mode != M_WINDOW))) continue;
+      if (mode == R_DONE) continue;
+      const double dx = qx[q] - tx, dy = qy[q] - ty, dz = qz[q] - tz;
+      const double d = (dx * dx + dy * dy) + dz * dz;   // knn_cpu.cpp:43-50 order, unfused
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
+      const bool valid = in && d == d;                  // a NaN distance is never a neighbour (strict '<' insertion, knn_cpu.cpp:46)
+      if (COLLECT) {
+        bool take;
+        if (mode == R_WINDOW) take = valid && win_key(bits) <= s[q].b0;
+        else if (mode == R_DBITS) take = valid && (s[q].m >= 64 ? bits : (bits >> (64 - s[q].m))) <= s[q].pfx;
+        else if (mode == R_INDEX) take = valid && (bits < s[q].pfx || (bits == s[q].pfx && (s[q].mi >= 32 ? idx : (idx >> (32 - s[q].mi))) <= s[q].ipfx));
+        else take = valid;
+        if (take) {
+          const unsigned int pos = atomicAdd(&pn[q], 1u);
+          if (pos < (unsigned int)kCap) { pd[q][pos] = d; pi[q][pos] = (int)idx; }
+        }
+      } else {
+        bool ok;
+        int dg;
+        if (mode == M_WINDOW) { dg = win_key(bits); ok = valid && dg <= s[q].filter; }
+        else if (mode == M_DBITS) {
+          const int m = s[q].m, w = 64 - m < 10 ? 64 - m : 10;
+          ok = valid && (m == 0 || (bits >> (64 - m)) == s[q].pfx);
+          dg = (int)((bits >> (64 - m - w)) & ((1ull << w) - 1ull));
+        } else {
+          const int mi = s[q].mi, w = 32 - mi < 10 ? 32 - mi : 10;
+          ok = valid && bits == s[q].pfx && (mi == 0 || (idx >> (32 - mi)) == s[q].ipfx);
+          dg = (int)((idx >> (32 - mi - w)) & ((1u << w) - 1u));
+        }
+        // one LDS update per distinct key of the wave: neighbouring targets lie at similar distances, and 64 lanes adding
+        // to one address are served one after the other
+        unsigned long long act = __ballot(ok);
+        while (act) {
+          const int L = (int)__builtin_ctzll(act);
+          const int dL = __builtin_amdgcn_readlane(dg, L);
+          const unsigned long long same = __ballot(ok && dg == dL);
+          if (lane == L) atomicAdd(&hist[q][dL], (unsigned int)__builtin_popcountll(same));
+          act &= ~same;
+        }
+      }
+    }
+  }
+}
+
+// pass A / pass B: four targets per thread and trip, the next four already in flight.
+//   BOUND:   per-thread minimum of d² per query (a NaN never replaces a number)
+//   !BOUND:  collect the targets with bits(d²) <= lim[q] (a limit of 0 with take0[q] false: the query takes no part)
+template <bool BOUND>
+__device__ __forceinline__ void sweep_pass(const KnnBruteArgs& a, const double (&qx)[kQB], const double (&qy)[kQB], const double (&qz)[kQB],
+                                           int nq, double (&mn)[kQB], const unsigned long long (&lim)[kQB], const bool (&part)[kQB],
+                                           double (*pd)[kCap], int (*pi)[kCap], unsigned int* pn, int64_t n_steps) {
+  constexpr int U = 4;
+  const int tid = threadIdx.x;
+  double tx[U], ty[U], tz[U], nx[U], ny[U], nz[U];
+  // Which thread sees which target decides how good the bound is: scan order is (azimuth, beam), so with thread = j mod 1024
+  // the neighbours of a query — a few beams x a few dozen azimuths — all fall to the same ~30 threads and the K-th smallest
+  // of the minima lies far out.  Each block of 1024 targets is therefore rotated by a pseudo-random amount (a wave
+  // still reads 64 consecutive rows, wrap-around aside): the blocks' neighbours land on different threads.
+  auto target_of = [&](int64_t step) -> int64_t {
+    const unsigned int rot = ((unsigned int)step * 0x9E3779B1u) >> 22;
+    return step * kNTB + (int64_t)(((unsigned int)tid + rot) & (unsigned int)(kNTB - 1));
+  };
+  auto fetch = [&](int64_t it, double (&x)[U], double (&y)[U], double (&z)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t j = target_of(it + u);
+      j = j < a.M ? j : 0;
+      const double* tp = a.tgt + 3 * j;
+      x[u] = tp[0]; y[u] = tp[1]; z[u] = tp[2];
+    }
+  };
+  fetch(0, nx, ny, nz);
+  for (int64_t it = 0; it < n_steps; it += U) {   // workgroup-uniform
+#pragma unroll
+    for (int u = 0; u < U; ++u) { tx[u] = nx[u]; ty[u] = ny[u]; tz[u] = nz[u]; }
+    if (it + U < n_steps) fetch(it + U, nx, ny, nz);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = target_of(it + u);
+      const bool in = j < a.M;
+#pragma unroll
+      for (int q = 0; q < kQB; ++q) {
+        if (q >= nq) break;
+        const double dx = qx[q] - tx[u], dy = qy[q] - ty[u], dz = qz[q] - tz[u];
+        const double d = (dx * dx + dy * dy) + dz * dz;   // knn_cpu.cpp:43-50 order, unfused
+        if (BOUND) {
+          if (in && d < mn[q]) mn[q] = d;
+        } else {
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
+          if (in && part[q] && bits <= lim[q]) {
+            const unsigned int pos = atomicAdd(&pn[q], 1u);
+            if (pos < (unsigned int)kCap) { pd[q][pos] = d; pi[q][pos] = (int)j; }
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kNTB) void k_knn_brute(KnnBruteArgs a) {
+  __shared__ unsigned int s_hist[kQB][kBins];
+  __shared__ double s_pd[kQB][kCap];
+  __shared__ int s_pi[kQB][kCap];
+  __shared__ unsigned int s_pn[kQB];
+  __shared__ QState s_st[kQB];
+  __shared__ int s_open;   // queries still selecting
+  __shared__ unsigned long long s_bound[kQB];
+  __shared__ double s_min[kQB][kNTB];   // pass A: the threads' minima
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int64_t qb0 = a.b_lo + (int64_t)blockIdx.x * kQB;
+  const int nq = (int)((a.b_hi - qb0) < kQB ? (a.b_hi - qb0) : kQB);
+  const int K = a.K;
+
+  double qx[kQB], qy[kQB], qz[kQB];
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) {
+    const int64_t b = qb0 + (q < nq ? q : 0);
+    const double sx = a.src[3 * b], sy = a.src[3 * b + 1], sz = a.src[3 * b + 2];
+    const double* R = a.pose.R0;
+    qx[q] = (sx * R[0] + sy * R[1] + sz * R[2]) + a.pose.t0[0];   // SVGDICP.cpp:204, as in the other stage-A kernels
+    qy[q] = (sx * R[3] + sy * R[4] + sz * R[5]) + a.pose.t0[1];
+    qz[q] = (sx * R[6] + sy * R[7] + sz * R[8]) + a.pose.t0[2];
+  }
+  for (int i = tid; i < kQB * kBins; i += kNTB) (&s_hist[0][0])[i] = 0u;
+  if (tid < kQB) s_pn[tid] = 0u;
+  __syncthreads();
+
+  // analysis of query `wave`'s histogram after a counting pass (one wave per query): the bin that holds the K'-th
+  // smallest among the counted targets, K' = K − below
+  auto analyse = [&](bool sample_pass) {
+    const int q = wave;
+    if (q < nq) {
+      QState st = s_st[q];
+      if (st.mode < R_WINDOW) {
+        constexpr int PL = kBins / kWave;   // bins per lane
+        unsigned int h[PL];
+        unsigned int mine = 0u;
+#pragma unroll
+        for (int i = 0; i < PL; ++i) { h[i] = s_hist[q][lane * PL + i]; mine += h[i]; }
+        unsigned int incl = mine;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { const unsigned int o = __shfl_up(incl, off, kWave); if (lane >= off) incl += o; }
+        const unsigned int total = __shfl(incl, kWave - 1, kWave);
+        const unsigned int want = (unsigned int)(K - st.below);   // >= 1
+        if (total < want) {
+          // fewer counted targets than asked for: only without a filter, i.e. fewer than K valid targets in all
+          if (sample_pass) st.filter = kBins - 1;
+          else { st.mode = R_ALL; }
+        } else {
+          const unsigned int excl = incl - mine;
+          const bool here = excl < want && want <= incl;   // exactly one lane
+          int bin = 0;
+          unsigned int before = 0u, inbin = 0u;
+          if (here) {
+            unsigned int c = excl;
+#pragma unroll
+            for (int i = 0; i < PL; ++i) {
+              if (c < want && want <= c + h[i]) { bin = lane * PL + i; before = c; inbin = h[i]; }
+              c += h[i];
+            }
+          }
+          const int src_lane = (int)__builtin_ctzll(__ballot(here));
+          bin = __shfl(bin, src_lane, kWave); before = __shfl(before, src_lane, kWave); inbin = __shfl(inbin, src_lane, kWave);
+          if (sample_pass) st.filter = bin;
+          else if (st.mode == M_WINDOW) {
+            if (before + inbin <= (unsigned int)kCap) { st.mode = R_WINDOW; st.b0 = bin; }
+            else { st.mode = M_DBITS; st.m = 0; st.pfx = 0ull; st.below = 0; }   // general path, from the top bits
+          } else if (st.mode == M_DBITS) {
+            const int w = 64 - st.m < 10 ? 64 - st.m : 10;
+            st.below += (int)before; st.pfx = (st.pfx << w) | (unsigned long long)bin; st.m += w;
+            if ((unsigned int)st.below + inbin <= (unsigned int)kCap) st.mode = R_DBITS;
+            else if (st.m >= 64) { st.mode = M_INDEX; st.mi = 0; st.ipfx = 0u; }
+          } else {
+            const int w = 32 - st.mi < 10 ? 32 - st.mi : 10;
+            st.below += (int)before; st.ipfx = (st.ipfx << w) | (unsigned int)bin; st.mi += w;
+            if ((unsigned int)st.below + inbin <= (unsigned int)kCap || st.mi >= 32) st.mode = R_INDEX;
+          }
+        }
+        if (lane == 0) { s_st[q] = st; if (st.mode < R_WINDOW) atomicAdd(&s_open, 1); }
+        for (int i = lane; i < kBins; i += kWave) s_hist[q][i] = 0u;
+      }
+    }
+  };
+
+  const int64_t steps_all = (a.M + kNTB - 1) / kNTB;
+  long long t_prev = a.phase_cycles ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  auto stamp = [&](int ph) {   // debug = 1: cycles of thread 0 per phase, summed over the workgroups
+    if (a.phase_cycles && tid == 0) { const long long t = (long long)__builtin_amdgcn_s_memtime(); atomicAdd(&a.phase_cycles[ph], (unsigned long long)(t - t_prev)); t_prev = t; }
+  };
+  unsigned long long lim[kQB];
+  bool part[kQB];
+  // pass A: per-thread minima -> a bound at least K targets meet
+  {
+    double mn[kQB];
+#pragma unroll
+    for (int q = 0; q < kQB; ++q) { mn[q] = __builtin_huge_val(); lim[q] = 0ull; part[q] = false; }
+    sweep_pass<true>(a, qx, qy, qz, nq, mn, lim, part, s_pd, s_pi, s_pn, steps_all);
+#pragma unroll
+    for (int q = 0; q < kQB; ++q) s_min[q][tid] = mn[q];
+  }
+  __syncthreads();
+  stamp(0);
+  if (wave < nq) {   // wave q: the K-th smallest of query q's 1024 minima, bit by bit (non-negative doubles order like their bits)
+    const int q = wave;
+    constexpr int NK = kNTB / kWave;
+    // on the high words only (sign, exponent, 20 mantissa bits): the bound is the K-th smallest high word with all low bits
+    // set — 2^-20 looser than the K-th minimum itself, half the iterations and 32-bit compares
+    unsigned int key[NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) key[i] = (unsigned int)((unsigned long long)__double_as_longlong(s_min[q][lane + kWave * i]) >> 32);
+    unsigned int vh = 0u;
+    for (int bit = 30; bit >= 0; --bit) {   // +inf (a thread without a target) is 0x7ff00000: bit 31 is never needed
+      const unsigned int cand = vh | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < NK; ++i) c += __builtin_popcountll(__ballot(key[i] < cand));
+      if (c < K) vh = cand;   // fewer than K minima below: the K-th is at or above the candidate
+    }
+    const unsigned long long v = vh >= 0x7ff00000u ? 0x7ff0000000000000ull : (((unsigned long long)vh << 32) | 0xffffffffull);
+    if (lane == 0) s_bound[q] = v;   // fewer than K targets in all: v = +inf's bits — every number passes
+  }
+  __syncthreads();
+  stamp(1);
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) {
+    const unsigned long long l = s_bound[q < nq ? q : 0];
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)l), hi = __builtin_amdgcn_readfirstlane((unsigned int)(l >> 32));
+    lim[q] = ((unsigned long long)hi << 32) | lo;
+    part[q] = q < nq;
+  }
+  // pass B: collect within the bound
+  {
+    double mn[kQB] = {0.0, 0.0, 0.0, 0.0};
+    sweep_pass<false>(a, qx, qy, qz, nq, mn, lim, part, s_pd, s_pi, s_pn, steps_all);
+  }
+  __syncthreads();
+  stamp(2);
+  // overflow (more than 256 targets within the bound): those queries go through the histogram / general path, the
+  // window key of the bound as the filter
+  bool general = false;
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) general = general || (q < nq && s_pn[q] > (unsigned int)kCap);
+  if (general) {   // workgroup-uniform
+    __syncthreads();
+    if (tid < kQB) {
+      QState z{};
+      if (tid < nq && s_pn[tid] > (unsigned int)kCap) { z.mode = M_WINDOW; z.filter = win_key(s_bound[tid]); s_pn[tid] = 0u; }
+      else z.mode = R_DONE;
+      s_st[tid] = z;
+    }
+    __syncthreads();
+    for (int round = 0; round < 13; ++round) {   // window histogram, then 7 + 4 rounds at most
+      brute_pass<false>(a, qx, qy, qz, nq, s_st, s_hist, s_pd, s_pi, s_pn, 0, 1, steps_all, false);
+      __syncthreads();
+      if (tid == 0) s_open = 0;
+      __syncthreads();
+      analyse(false);
+      __syncthreads();
+      if (s_open == 0) break;
+      __syncthreads();
+    }
+    brute_pass<true>(a, qx, qy, qz, nq, s_st, s_hist, s_pd, s_pi, s_pn, 0, 1, steps_all, false);
+    __syncthreads();
+  }
+  stamp(3);
+
+  // rank by counting under (d², original index), ascending output (pad like torch::full(..., 0), knn_cpu.cpp:25-26)
+  {   // threads [256 q, 256 q + 256) rank query q's pool
+    const int q = tid >> 8, e = tid & 255;
+    if (q < nq) {
+      const int64_t b = qb0 + q;
+      const int n = (int)(s_pn[q] < (unsigned int)kCap ? s_pn[q] : (unsigned int)kCap);
+      if (e < n) {
+        const double de = s_pd[q][e];
+        const int ie = s_pi[q][e];
+        int rank = 0;
+        int f = 0;
+        for (; f + 8 <= n; f += 8) {   // eight broadcast reads in flight per trip (one at a time, the loop waits out the LDS latency)
+          double df[8];
+          int jf[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { df[u] = s_pd[q][f + u]; jf[u] = s_pi[q][f + u]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) rank += (df[u] < de || (df[u] == de && jf[u] < ie)) ? 1 : 0;
+        }
+        for (; f < n; ++f) {
+          const double df = s_pd[q][f];
+          const int jf = s_pi[q][f];
+          rank += (df < de || (df == de && jf < ie)) ? 1 : 0;
+        }
+        if (rank < K) { a.out_idx[b * K + rank] = ie; a.out_d2[b * K + rank] = de; }
+      }
+      for (int k = n + e; k < K; k += 256) { a.out_idx[b * K + k] = 0; a.out_d2[b * K + k] = 0.0; }
+    }
+  }
+  stamp(4);
+}
+
+}  // namespace
+
+// the sizes this kernel is for: every pair is evaluated two or three times in float64
+bool knn_brute_applicable(int64_t B, int64_t M, int K) {
+  return K >= 1 && K <= 128 && B >= 1 && M >= 1 && M < (1ll << 31) && (double)B * (double)M <= 134217728.0;   // 2^27 pairs
+}
+
+hipError_t launch_knn_brute(const KnnBruteArgs& a, hipStream_t st) {
+  const int64_t n = a.b_hi - a.b_lo;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_knn_brute, dim3((unsigned)((n + kQB - 1) / kQB)), dim3(kNTB), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace svnicp

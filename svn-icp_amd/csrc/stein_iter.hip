@@ -79,6 +79,102 @@ __device__ inline void single_particle_tail(const AccumArgs& a, const UpdateArgs
   if (tid == 0) update_single_particle(u, sums);
 }
 
+// ONE particle: the whole iteration in one launch, lanes along the SOURCE POINTS.  The stage-B kernels put particles on
+// the lanes (lane <-> particle): with one particle 63 of 64 lanes idle and an iteration of BASELINE C1 (4 096 points, K = 100)
+// took 34 us.  Here four lanes share a source point and a quarter of its K candidates each (float64 rows of `table`, the
+// reference's arithmetic and first-index tie rule: strict '<' in ascending k inside a lane, (d², k) order across the four),
+// the first of the four accumulates the 22 sums of its point, the wave and the workgroup fold them in a fixed order, and the
+// last workgroup to finish reduces the workgroups' partial sums and runs the Stein step (single_particle_tail).
+__global__ __launch_bounds__(NT) void k_icp_single(AccumArgs a, UpdateArgs u) {
+  if (a.ctl[0]) return;  // early stop already signalled (SVNICP.cpp:95-101)
+  __shared__ double s_red[4][kNSums];
+  __shared__ double s_tail[12 * (kNSums + 1) + kNSums];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int sub = lane & 3, ptl = lane >> 2;
+  const int64_t b = (int64_t)blockIdx.x * 64 + wave * 16 + ptl;
+  const bool inb = b < a.B;
+  const int64_t bl = inb ? b : a.B - 1;
+  const int K = a.K;
+  const double* rp = a.Rtot + 12 * (size_t)a.p_lo;
+  const double* sp = a.src + 3 * bl;
+  const double s0 = sp[0], s1 = sp[1], s2 = sp[2];
+  const double T0 = (s0 * rp[0] + s1 * rp[1] + s2 * rp[2]) + rp[9];    // SVNICP.cpp:62-64
+  const double T1 = (s0 * rp[3] + s1 * rp[4] + s2 * rp[5]) + rp[10];
+  const double T2 = (s0 * rp[6] + s1 * rp[7] + s2 * rp[8]) + rp[11];
+  const double* row = a.table + (size_t)bl * K * 3;
+  double bd = __builtin_huge_val(), d_first = 0.0;
+  int bk = 0x7fffffff;
+  constexpr int U = 5;   // candidates per lane and trip: their loads go out together
+  for (int k0 = sub; k0 < K; k0 += 4 * U) {
+    double x[U], y[U], z[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int k = k0 + 4 * i;
+      const double* r = row + 3 * (k < K ? k : 0);
+      x[i] = r[0]; y[i] = r[1]; z[i] = r[2];
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int k = k0 + 4 * i;
+      const double dx = T0 - x[i], dy = T1 - y[i], dz = T2 - z[i];
+      const double d = (dx * dx + dy * dy) + dz * dz;   // knn_cpu.cpp:43-50 order, unfused
+      if (k == 0) d_first = d;
+      if (k < K && d < bd) { bd = d; bk = k; }          // strict: the first k wins ties (knn_cpu.cpp:52 with K = 1)
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 4; off <<= 1) {
+    const double od = __shfl_xor(bd, off, kWave);
+    const int ok = __shfl_xor(bk, off, kWave);
+    if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
+  }
+  const double d0 = __shfl(d_first, lane & ~3, kWave);
+  // the serial reference loop starts from candidate 0 and only replaces on '<': a NaN first distance is never replaced
+  const int kb = (d0 != d0 || bk == 0x7fffffff) ? 0 : bk;
+
+  double acc[kNSums];
+#pragma unroll
+  for (int i = 0; i < kNSums; ++i) acc[i] = 0.0;
+  if (sub == 0 && inb) {
+    if (a.corr) a.corr[(size_t)a.p_lo * a.B + b] = kb;
+    const double* r = row + 3 * kb;
+    const double dx = T0 - r[0], dy = T1 - r[1], dz = T2 - r[2];
+    const double best = (dx * dx + dy * dy) + dz * dz;
+    double w = 1.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
+    if (best < a.max_dist) {  // point_filter, SVGDICP.cpp:331-333
+      const double n = sqrt(best);                      // ‖Ts − q‖, SVNICP.cpp:120
+      const double wq = a.max_dist / (a.max_dist + 3 * n);
+      w = wq * wq;                                      // SVNICP.cpp:122
+      e0 = w * dx; e1 = w * dy; e2 = w * dz;            // SVNICP.cpp:119,123
+      m0 = s0; m1 = s1; m2 = s2;
+    }
+    const double w0 = w * m0, w1 = w * m1, w2 = w * m2;
+    acc[0] = w;
+    acc[1] = w0; acc[2] = w1; acc[3] = w2;
+    // SVGD mode needs count_nonzero(mask·Ts summed over xyz) (SVGDICP.cpp:404) instead of Σw·s_x²
+    acc[4] = a.svgd ? ((best < a.max_dist && ((T0 + T1) + T2) != 0.0) ? 1.0 : 0.0) : w0 * m0;
+    acc[5] = w0 * m1; acc[6] = w0 * m2;
+    acc[7] = w1 * m1; acc[8] = w1 * m2; acc[9] = w2 * m2;
+    acc[10] = e0; acc[11] = e1; acc[12] = e2;
+    acc[13] = e0 * m0; acc[14] = e0 * m1; acc[15] = e0 * m2;
+    acc[16] = e1 * m0; acc[17] = e1 * m1; acc[18] = e1 * m2;
+    acc[19] = e2 * m0; acc[20] = e2 * m1; acc[21] = e2 * m2;
+  }
+  // fixed-order reduction: the wave's 16 points, the workgroup's four waves, then (tail) the workgroups in block order
+#pragma unroll
+  for (int off = 4; off < kWave; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < kNSums; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < kNSums; ++i) s_red[wave][i] = acc[i];
+  }
+  __syncthreads();
+  if (tid < kNSums) a.partial[((size_t)blockIdx.x * a.Ppad) * kNSums + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+  single_particle_tail(a, u, s_tail);
+}
+
 template <int PW, int WP>
 __global__ __launch_bounds__(NT) void k_stein_accumulate(AccumArgs a, UpdateArgs u, int fuse_single) {
   if (a.ctl[0]) return;  // early stop already signalled (SVNICP.cpp:95-101)
@@ -528,12 +624,17 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
 
 // single != nullptr (one particle, fused f32 kernel, no exchange between ranks): the kernel's last workgroup also reduces
 // the partial sums and runs the Stein step — the caller launches neither k_reduce_partials nor an update kernel
-bool accumulate_can_fuse_single(const AccumPlan& plan) { return plan.f32 == 1 && plan.smem >= (size_t)(12 * (kNSums + 1)) * sizeof(double); }
+bool accumulate_can_fuse_single(const AccumPlan& plan) { return plan.f32 == 1; }
+int single_particle_grid(int64_t B) { return (int)((B + 63) / 64); }
 hipError_t launch_accumulate(const AccumPlan& plan, AccumArgs a, const UpdateArgs* single, hipStream_t st) {
   a.TP = plan.TP; a.RS = plan.RS; a.tiles_per_block = plan.tiles_per_block; a.n_tiles = plan.n_tiles;
   a.Ppad = plan.Ppad;
   a.pts_per_block = plan.pts_per_block; a.spts_per_block = plan.spts_per_block;
   if (plan.f32 == 3) return launch_accumulate_split(plan, a, st);
+  if (single && plan.f32 == 1) {   // one particle: lanes along the source points, reduce + Stein step in the last workgroup
+    hipLaunchKernelGGL(k_icp_single, dim3(single_particle_grid(a.B)), dim3(NT), 0, st, a, *single);
+    return hipGetLastError();
+  }
   switch (plan.PW) {
     case 8: return launch_t<8, 1>(plan, a, single, st);
     case 16: return launch_t<16, 1>(plan, a, single, st);

@@ -272,9 +272,10 @@ def test_full_correspondence_mode_refusals(hip):
 @pytest.mark.parametrize("B,M,K", [(700, 20000, 7), (300, 9000, 1), (1000, 16384, 128), (513, 8192, 100), (64, 40000, 33),
                                    (900, 12000, 150)])
 def test_stage_a_variants_bit_exact(hip, orc, B, M, K):
-    """The three stage-A kernels — streaming (knn_topk.hip, option knn=v1), seeded f32 pre-filter
-    (knn_scan.hip, v2) and Morton-tile pruning (knn_tiles.hip, default for K <= 128) — must all give
-    indices and dist² bit-identical to the oracle's f64 brute force."""
+    """The four stage-A kernels — streaming (knn_topk.hip, option knn=v1), seeded f32 pre-filter
+    (knn_scan.hip, v2), Morton-tile pruning (knn_tiles.hip, K <= 128) and the one-launch brute force for small
+    registrations (knn_brute.hip, the default up to 2^27 point pairs and K <= 128) — must all give indices and dist²
+    bit-identical to the oracle's f64 brute force."""
     src, tgt = hip.scans.random_clouds(B, M, seed=B + K, extent=40.0)
     src = src + np.array([100.0, -50.0, 3.0])      # large coordinates: the filter slack must cover them
     tgt = tgt + np.array([100.0, -50.0, 3.0])
@@ -282,7 +283,9 @@ def test_stage_a_variants_bit_exact(hip, orc, B, M, K):
     cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
     oi, od = orc.knn_topk(src, tgt, K)
     fbs = {}
-    for variant in ("v1", "v2", "default"):
+    for variant in ("v1", "v2", "tiles", "brute", "default"):
+        if variant == "brute" and K > 128:
+            continue
         s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init)
         if variant != "default":
             s.set_option("knn", variant)
@@ -296,9 +299,10 @@ def test_stage_a_variants_bit_exact(hip, orc, B, M, K):
     assert fbs["v1"] == -1
     assert 0 <= fbs["v2"] <= max(2, B // 100)       # the probabilistic seed is good: (almost) nothing falls back
     if K > 128:
-        assert fbs["default"] == fbs["v2"]          # knn_tiles does not apply: the default is the v2 kernel
+        assert fbs["default"] == fbs["v2"] and fbs["tiles"] == fbs["v2"]   # neither knn_tiles nor knn_brute applies: the v2 kernel
     else:
-        assert 0 <= fbs["default"] <= max(2, B // 100)  # guaranteed seed + in-kernel overflow recovery
+        assert 0 <= fbs["tiles"] <= max(2, B // 100)    # guaranteed seed + in-kernel overflow recovery
+        assert fbs["brute"] == 0 and fbs["default"] == 0    # these sizes default to the brute-force kernel, which never falls back
 
 
 @pytest.mark.parametrize("sliced_max,K", [(None, 50), ("0", 50), ("100", 50), (None, 128), (None, 7)])
@@ -316,11 +320,41 @@ def test_stage_a_fallback_on_pool_overflow(hip, orc, sliced_max, K):
     init = np.zeros((6, 1))
     cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
     s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init)
+    s.set_option("knn", "tiles")          # the default at this size is the brute-force kernel (next test)
     if sliced_max is not None:
         s.set_option("fallback_sliced_max", sliced_max)
     s.stein_align()
     assert s.get_knn_fallbacks() == 300
     oi, od = orc.knn_topk(src, tgt, K)
+    assert np.array_equal(s.get_candidates().astype(np.int64), oi)
+    assert np.array_equal(s.get_candidate_dist2(), od)
+
+
+@pytest.mark.parametrize("K", [1, 7, 50, 128])
+def test_stage_a_brute_force_exact_ties(hip, orc, K):
+    """knn_brute.hip's general path: 2000 targets at exactly the same distance put far more than 256 entries below the
+    K-th bin, so the selection goes through the full 64 bits of d² and then through the index bits of the exact ties
+    (lowest index wins, as everywhere); a query ON a duplicated target has d² = 0 (below the key window); fewer targets
+    than K pad with zeros."""
+    rng = np.random.default_rng(3)
+    centers = rng.normal(size=(6, 3)) * 5
+    tgt = np.repeat(centers, 2000, axis=0).astype(np.float32).astype(np.float64)   # M = 12000, 2000 duplicates each
+    tgt = tgt[rng.permutation(tgt.shape[0])]
+    src = (centers[rng.integers(0, 6, 301)] + rng.normal(size=(301, 3)) * 0.1)
+    src[:6] = tgt[:6]                                   # d² = 0 against 2000 targets each
+    init = np.zeros((6, 1))
+    cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
+    s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src, tgt, init)
+    s.stein_align()
+    assert s.get_knn_fallbacks() == 0
+    oi, od = orc.knn_topk(src, tgt, K)
+    assert np.array_equal(s.get_candidates().astype(np.int64), oi)
+    assert np.array_equal(s.get_candidate_dist2(), od)
+    # fewer targets than K
+    small = tgt[: max(2, K // 2)].copy()
+    s = _hip_solver(hip, init, trace=False, **cfg); s.add_cloud(src[:37], small, init)
+    s.stein_align()
+    oi, od = orc.knn_topk(src[:37], small, K)
     assert np.array_equal(s.get_candidates().astype(np.int64), oi)
     assert np.array_equal(s.get_candidate_dist2(), od)
 

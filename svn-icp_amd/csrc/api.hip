@@ -420,6 +420,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "group_stride") ok = num(0, 1 << 30, &t.group_stride);
   else if (k == "accum_min_steps") ok = num(0, 1 << 20, &t.accum_min_steps);
   else if (k == "single") { if (v == "fused") t.single_fused = 1; else if (v == "split") t.single_fused = 0; else ok = false; }
+  else if (k == "chain") { if (v == "auto") t.small_chain = 1; else if (v == "general") t.small_chain = 0; else ok = false; }
   else if (k == "correspondence") { if (v == "fast") t.full_corr = 0; else if (v == "full") t.full_corr = 1; else ok = false; }
   else return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: unknown option '" + k + "'");
   if (!ok) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: bad value '" + v + "' for option '" + k + "'");
@@ -542,7 +543,11 @@ int svnicp_align_begin(svnicp_ctx* c) {
   c->hist_I = I; c->hist_P = P;
   const int nshard = c->p_hi - c->p_lo;
   if (nshard > 0) {
-    c->plan = plan_accumulate(nshard, B, c->K, c->num_cus, c->accum_mode, c->tune);
+    // small chain (few pairs, one context holds everything, 2 <= P <= 128): decided here, carried by the plan
+    Tuning tn = c->tune;
+    tn.small_chain = tn.small_chain && P >= 2 && P <= 128 && P <= tn.fused_update_max_p && !tn.update_fused && c->row_world == 1 &&
+                     c->p_lo == 0 && c->p_hi == P && !tn.full_corr;
+    c->plan = plan_accumulate(nshard, B, c->K, c->num_cus, c->accum_mode, tn);
     if (c->tune.debug)
       fprintf(stderr, "[svnicp] stage-B plan: mode=%d PW=%d WP=%d TP=%d grid=%dx%d tiles/block=%d smem=%zu sgrid=%d pts/block=%d/%d\n", c->plan.f32,
               c->plan.PW, c->plan.WP, c->plan.TP, c->plan.grid_x, c->plan.grid_y, c->plan.tiles_per_block, c->plan.smem,
@@ -780,8 +785,12 @@ static bool update_one_kernel(const svnicp_ctx* c) { return c->P < 2 || (c->tune
 // the pair statistics of iteration `it` (bandwidth h from the exact median of the pair distances): they depend on the
 // poses only, so they are forked onto the second stream at the START of the iteration and run beside the search and
 // accumulate kernels; svnicp_iter_update joins before the Stein direction
+// few (point, particle) pairs: the accumulate kernel runs at most kSmallChainBlocks workgroups, nothing reduces their records
+// (the prepare lanes add them), and the pair statistics share the prepare kernel's launch on the main stream
+static bool small_chain(const svnicp_ctx* c) { return c->plan.f32 == 3 && c->plan.small && c->plan.grid_x <= kSmallChainBlocks; }
+
 static int fork_median(svnicp_ctx* c, int it) {
-  if (update_one_kernel(c) || c->median_pending) return SVNICP_OK;
+  if (update_one_kernel(c) || c->median_pending || small_chain(c)) return SVNICP_OK;
   if (c->tune.debug && !c->dbg_upd) { HIPCHK(c, hipMalloc(&c->dbg_upd, 8 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->dbg_upd, 0, 8 * sizeof(unsigned long long))); }
   const UpdateArgs u = update_args(c, it);
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -838,6 +847,7 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   HIPCHK(c, launch_accumulate(c->plan, a, single ? &us : nullptr, c->stream));
   HIPCHK(c, prof_end(c));
   if (single) { c->single_done_it = it; return SVNICP_OK; }
+  if (small_chain(c)) return SVNICP_OK;   // the update kernels add the workgroups' records themselves
   HIPCHK(c, prof_begin(c, KC_REDUCE));
   // one rank: the particle's record; source-row sharding: this rank's slot of the [row_world][P][22] array
   double* rec = c->row_world > 1 ? c->rank_sums.p + (size_t)c->row_rank * c->P * kNSums : c->sums.p;
@@ -866,6 +876,10 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
     u.svgd = 0;   // the one-workgroup kernels are per mode
     if (c->prm.mode == SVNICP_MODE_SVGD) HIPCHK(c, launch_update_svgd(u, c->stream));
     else HIPCHK(c, launch_update(u, c->stream));
+  } else if (small_chain(c)) {
+    u.sums = c->partial.p; u.n_ranks = c->plan.grid_x; u.sums_stride = c->plan.Ppad * kNSums; u.sums_out = c->sums.p;
+    HIPCHK(c, launch_update_prepare_median(u, c->stream));
+    HIPCHK(c, launch_update_direction(u, c->stream));
   } else {
     // pair statistics: forked at the start of the iteration; a caller that skipped svnicp_iter_accumulate gets them here
     if (const int rc = fork_median(c, it)) return rc;

@@ -152,7 +152,9 @@ struct AccumArgs {
   int pts_per_block, spts_per_block;  // split variant: source points per workgroup (accumulate / search kernel)
   unsigned int* ticket;               // fused one-particle iteration: arrival counter of the accumulate kernel's workgroups
 };
-struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem; };
+struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem;
+                   int small; /* split variant, few (point, particle) pairs: at most kSmallChainBlocks accumulate workgroups, see api.hip small_chain */ };
+constexpr int kSmallChainBlocks = 32;
 // f32: 0 = float64 baseline, 1 = float32 VALU search (fused with the accumulation), 3 = bf16 matrix-pipe search kernel +
 // accumulation kernel (falls back to 1 when K > 128 or the shard has <= 8 particles)
 // test / profiling knobs of a context (svnicp_set_option); the defaults are the product configuration
@@ -169,6 +171,7 @@ struct Tuning {
   int scan_split = 0;            // stage A scan: waves per 64-query workgroup, 4 or 8 (0 = default)
   int debug = 0;                 // print plans and per-phase cycle counters to stderr
   int single_fused = 1;          // one particle: reduce + Stein step in the accumulate kernel's last workgroup (0: three launches, A/B)
+  int small_chain = 1;           // small registrations: no k_reduce_partials, Stein-step front in one launch on the main stream (0: the general chain, A/B)
   int full_corr = 0;             // 1: correspondence = full — per-particle exact NN over the whole target (SVGDICP.cpp:274-298)
 };
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune);
@@ -186,6 +189,8 @@ hipError_t launch_transform_cloud(const double* src, int64_t B, const double* po
 struct UpdateArgs {
   const double* sums;  // [P][kNSums] (all particles); source-row sharding: [n_ranks][P][kNSums], summed in rank order on load
   int n_ranks;         // 1, or the number of row-shard records behind `sums`
+  int sums_stride;     // doubles between two records of `sums` (0: P * kNSums); small chain: the accumulate kernel's partial rows
+  double* sums_out;    // small chain: k_upd_prepare stores each particle's reduced record here, or nullptr
   double* R;           // [P][9]
   double* t;           // [P][3]
   double* Rtot;        // [P][12]
@@ -223,6 +228,7 @@ hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
 // Newton steps, direction + pose update
 hipError_t launch_update_median(const UpdateArgs& a, int num_cus, int max_p_one_workgroup, hipStream_t st);
 hipError_t launch_update_prepare(const UpdateArgs& a, hipStream_t st);
+hipError_t launch_update_prepare_median(const UpdateArgs& a, hipStream_t st);   // small chain: both in one launch (2 <= P <= 128)
 hipError_t launch_update_direction(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles, double* sums, const int* ctl,
                                   hipStream_t st);

@@ -31,12 +31,15 @@ struct Work {
 // The 22 raw sums of particle p.  One rank (or particle sharding): the context's own record.  Source-row sharding
 // (svnicp_set_row_shard): a.sums is the all-gathered [n_ranks][P][22] array of the ranks' partial records — rank r summed
 // its own source rows — and every rank adds the same records in the same (rank) order, so the replicas stay bit-identical.
+// Small registrations (api.hip: small chain): a.sums is the accumulate kernel's `partial` array itself — one record per
+// workgroup, record stride sums_stride — added here in block order: no k_reduce_partials launch.
 __device__ __forceinline__ void load_sums(const UpdateArgs& a, int p, double* s) {
   const double* rec = a.sums + (size_t)p * kNSums;
+  const size_t stride = a.sums_stride ? (size_t)a.sums_stride : (size_t)a.P * kNSums;
 #pragma unroll
   for (int i = 0; i < kNSums; ++i) s[i] = rec[i];
   for (int r = 1; r < a.n_ranks; ++r) {
-    rec += (size_t)a.P * kNSums;
+    rec += stride;
 #pragma unroll
     for (int i = 0; i < kNSums; ++i) s[i] += rec[i];
   }
@@ -437,14 +440,16 @@ __device__ double svgd_step_one(const UpdateArgs& a, int p, const double* phi6, 
 constexpr int PREP_T = 256, PREP_CH = 128, PREP_PW = 64;
 struct PrepShared { double H[PREP_CH][37]; double Hmean[36]; };   // 37.3 KB
 
-__global__ __launch_bounds__(PREP_T) void k_upd_prepare(UpdateArgs a) {
+// bx: workgroup index inside the prepare part of the launch (the block may have more than PREP_T threads: the others only
+// pass the barriers)
+__device__ __forceinline__ void prepare_body(const UpdateArgs& a, int bx) {
   if (a.ctl[0]) return;
   __shared__ PrepShared sh;
   const int tid = threadIdx.x, P = a.P;
   Work w(a.work, P);
   const int n_pw = (P + PREP_PW - 1) / PREP_PW;
-  if ((int)blockIdx.x < n_pw) {
-    const int p = blockIdx.x * PREP_PW + tid;
+  if (bx < n_pw) {
+    const int p = bx * PREP_PW + tid;
     if (tid >= PREP_PW || p >= P) return;
     if (a.svgd) {
       double g6[6];
@@ -457,6 +462,10 @@ __global__ __launch_bounds__(PREP_T) void k_upd_prepare(UpdateArgs a) {
     int piv[6];
     mat3_mul(a.pose.R0, a.R + 9 * p, Rc);
     load_sums(a, p, sm);
+    if (a.sums_out) {   // small chain: the reduced record, where k_reduce_partials would have left it (svnicp_sums_devptr)
+#pragma unroll
+      for (int i = 0; i < kNSums; ++i) a.sums_out[(size_t)p * kNSums + i] = sm[i];
+    }
     finalize_Hb(sm, Rc, H, b);
 #pragma unroll
     for (int i = 0; i < 36; ++i) { w.H[(size_t)p * 36 + i] = H[i]; LU[i] = H[i]; }
@@ -501,6 +510,7 @@ __global__ __launch_bounds__(PREP_T) void k_upd_prepare(UpdateArgs a) {
     for (int r = 0; r < 6; ++r) a.uctl[UCTL_HINV + 6 * r + tid] = ok ? col[r] : __builtin_nan("");
   }
 }
+__global__ __launch_bounds__(PREP_T) void k_upd_prepare(UpdateArgs a) { prepare_body(a, (int)blockIdx.x); }
 
 // sums[p_lo + i][s] = Σ_blk partial[blk][i][s], block order fixed.  Workgroup = 16 entries × 16 block lanes; each block
 // lane walks blk = bl, bl+16, … with eight loads in flight and the 16 lanes are folded in order: deterministic, and
@@ -744,7 +754,7 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
 // the search and accumulate kernels; k_upd_direction (one wavefront per particle, pose update fused) waits for it.
 // Measured (debug stamps): the 8-pass LDS radix select took 60 % of the fused kernel's 63 us; this kernel takes 13.5 us.
 constexpr int FRONT_BUF = 2048;  // keys of the median's bin held in LDS (+8 slack for the unrolled ranking); more (degenerate input) -> 8-pass select
-__global__ __launch_bounds__(UT) void k_upd_median(UpdateArgs a) {
+__device__ __forceinline__ void median_body(const UpdateArgs& a) {
   if (a.ctl[0]) return;
   extern __shared__ __align__(16) double dyn[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
@@ -883,6 +893,16 @@ __global__ __launch_bounds__(UT) void k_upd_median(UpdateArgs a) {
   }
   stamp(4);
   if (tid == 0) a.uctl[UCTL_H] = (sh_nan ? __builtin_nan("") : med) / log((double)(P + 1));  // SVNICP.cpp:262
+}
+__global__ __launch_bounds__(UT) void k_upd_median(UpdateArgs a) { median_body(a); }
+
+// Small registrations: both halves of the Stein step's front in ONE launch on the main stream — the last workgroup runs the
+// pair statistics, the others the sums-dependent half.  At the scan-to-map loop's sizes every kernel of an iteration runs
+// at its launch latency, and the second stream's fork and join cost 6-8 us each: k_reduce_partials (the prepare lanes add
+// the workgroups' records themselves, load_sums), k_upd_median's own launch and both event waits fall away.
+__global__ __launch_bounds__(UT) void k_upd_prepare_median(UpdateArgs a) {
+  if (blockIdx.x + 1 == gridDim.x) median_body(a);
+  else prepare_body(a, (int)blockIdx.x);
 }
 
 // pose update of one particle (SVNICP.cpp:268-279); its step norm goes to uctl[UCTL_NORM + p]
@@ -1396,6 +1416,17 @@ hipError_t launch_update_median(const UpdateArgs& a, int num_cus, int max_p_one_
 hipError_t launch_update_prepare(const UpdateArgs& a, hipStream_t st) {
   const int need_mean = (!a.svgd && !a.full_grad) ? 1 : 0;   // only the default SVN branch preconditions with the mean Hessian
   hipLaunchKernelGGL(k_upd_prepare, dim3((a.P + PREP_PW - 1) / PREP_PW + need_mean), dim3(PREP_T), 0, st, a);
+  return hipGetLastError();
+}
+
+// 2 <= P <= 128 only (the one-workgroup pair statistics)
+hipError_t launch_update_prepare_median(const UpdateArgs& a, hipStream_t st) {
+  const int P = a.P;
+  const int need_mean = (!a.svgd && !a.full_grad) ? 1 : 0;
+  const size_t smem = (size_t)P * 6 * sizeof(double) + (size_t)(FRONT_BUF + 8) * sizeof(double) + (size_t)HB_NB * sizeof(unsigned int);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_upd_prepare_median), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_upd_prepare_median, dim3((P + PREP_PW - 1) / PREP_PW + need_mean + 1), dim3(UT), smem, st, a);
   return hipGetLastError();
 }
 

@@ -593,6 +593,14 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
       if (occ_a > 4) occ_a = 4;
     }
     size_grid(occ_a, &pl.grid_x, &pl.pts_per_block, tune.accum_min_steps > 0 ? tune.accum_min_steps : 4);
+    // few pairs (the scan-to-map loop's sizes): at most kSmallChainBlocks accumulate workgroups, so that the update kernels can
+    // add their records themselves and k_reduce_partials is not launched (api.hip: small_chain)
+    pl.small = (pl.grid_y == 1 && (int64_t)B * n_particles <= (1 << 19) && tune.small_chain) ? 1 : 0;
+    if (pl.small && pl.grid_x > kSmallChainBlocks) {
+      const int64_t spb = (steps + kSmallChainBlocks - 1) / kSmallChainBlocks;
+      pl.pts_per_block = (int)(spb * pass);
+      pl.grid_x = (int)((B + pl.pts_per_block - 1) / pl.pts_per_block);
+    }
     size_grid(occ_s, &pl.sgrid_x, &pl.spts_per_block, 1);
     pl.TP = pass; pl.n_tiles = 0; pl.tiles_per_block = 0;
     return pl;

@@ -556,6 +556,37 @@ def test_single_particle_fused_iteration(hip, orc, es):
         assert o.iterations_run() < I
 
 
+@pytest.mark.parametrize("P,full,mode", [(30, False, "svn"), (128, False, "svn"), (17, True, "svn"), (9, False, "svn"), (64, False, "svgd")])
+def test_small_chain_equals_general_chain(hip, orc, P, full, mode):
+    """Few (point, particle) pairs — the scan-to-map loop's sizes — run the small chain: at most 32 accumulate workgroups,
+    no k_reduce_partials (the prepare lanes add the workgroups' records in block order) and the pair statistics in the
+    prepare kernel's launch on the main stream.  Option chain=general keeps the general chain.  Same correspondences; poses
+    equal to rounding (the sums are grouped differently) and both equal to the oracle."""
+    B, M, K, I = 1100, 9000, 50, 8
+    src, tgt = hip.scans.random_clouds(B, M, seed=P + 7, extent=20.0)
+    init = hip.scans.make_particles(P, seed=P) * 0.2
+    cfg = dict(iterations=I, lr=1.0, max_dist=1.0, check_early_stop=False, convergence_threshold=1e-5, knn_count=K, svn_full_grad=full)
+    if mode == "svgd":
+        cfg = dict(cfg, lr=0.01, optimizer="Adam"); cfg.pop("svn_full_grad")
+        o = orc.Solver(init, mode=orc.MODE_SVGD, svn_full_grad=False, **cfg)
+        mk = lambda: _hip_svgd(hip, init, cfg)
+    else:
+        o = orc.Solver(init, **cfg)
+        mk = lambda: _hip_solver(hip, init, **cfg)
+    o.add_cloud(src, tgt, init); tro = o.enable_trace(); o.stein_align()
+    out = {}
+    for chain in ("auto", "general"):
+        s = mk(); s.set_option("chain", chain); s.add_cloud(src, tgt, init)
+        assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+        if mode == "svgd":
+            assert np.allclose(s.get_particles(), o.get_particles(), rtol=0, atol=TIGHT)
+        else:
+            _compare(s, o, tro, P)
+        out[chain] = (s.get_particles(), s.get_trace()["corr"])
+    assert np.array_equal(out["auto"][1], out["general"][1])
+    assert np.allclose(out["auto"][0], out["general"][0], rtol=0, atol=1e-10)
+
+
 # ------------------------------------------------------------------ split-phase ABI (multi-GPU path) on one GPU
 def test_split_phase_two_shards_equal_single_context(hip):
     """Two contexts on one GPU play two ranks: particle shards [0,P/2) and [P/2,P), candidate rows

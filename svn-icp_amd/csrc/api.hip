@@ -72,7 +72,7 @@ struct svnicp_ctx {
       stats, trH, trb, trN, trphi, trh;
   DevBuf<int32_t> pool_i, cand_idx, trcorr, torig, pool2, fail_list;
   DevBuf<float> txf, tyf, tzf, cmaxb;
-  DevBuf<float4> tablef, tablea, tail;
+  DevBuf<float4> tablef, tablea;
   DevBuf<uint8_t> kbest;
   DevBuf<int32_t> kidx;
   // source-row sharding (svnicp_set_row_shard): this context holds rows of a larger scan; its per-iteration sums are one of
@@ -264,7 +264,7 @@ void svnicp_destroy(svnicp_ctx* c) {
   c->eul.release(); c->opt.release(); c->uctl.release(); c->rank_sums.release(); c->stage_fail_count.release(); c->stage_fail_list.release();
   c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->order_t.release(); c->qorder.release(); c->stat_n.release(); c->bbox.release(); c->tile_box.release(); c->sort_tmp.release();
   c->full_q.release(); c->full_d2.release(); c->full_idx.release(); c->arena.release(); c->chunk_tab.release();
-  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->tail.release(); c->kbest.release(); c->kidx.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
+  c->pool_i.release(); c->torig.release(); c->pool2.release(); c->fail_list.release(); c->txf.release(); c->tyf.release(); c->tzf.release(); c->cmaxb.release(); c->tablef.release(); c->tablea.release(); c->kbest.release(); c->kidx.release(); c->sl_d.release(); c->sl_i.release(); c->fail_tau.release(); c->qrec.release(); c->anchor.release(); c->ambig.release(); c->emax.release(); c->fail_count.release(); c->cand_idx.release(); c->trcorr.release(); c->history.release(); c->ctl.release();
   if (c->dbg_phase) (void)hipFree(c->dbg_phase);
   if (c->dbg_upd) (void)hipFree(c->dbg_upd);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -561,7 +561,7 @@ int svnicp_align_begin(svnicp_ctx* c) {
     c->plan.f32 = c->accum_mode == 3 ? 1 : c->accum_mode;
   }
   if (c->plan.f32 != 3) HIPCHK(c, c->table.ensure((size_t)B * c->K * 3));  // the split variant gathers from the target cloud
-  if (c->plan.f32 == 3) { HIPCHK(c, c->tablea.ensure((size_t)B * 128)); HIPCHK(c, c->anchor.ensure((size_t)B * 3)); HIPCHK(c, c->tail.ensure((size_t)B * 4)); }
+  if (c->plan.f32 == 3) { HIPCHK(c, c->tablea.ensure((size_t)B * 128)); HIPCHK(c, c->anchor.ensure((size_t)B * 3)); }
   if (c->plan.f32 == 3) { HIPCHK(c, c->kbest.ensure((size_t)B * c->plan.Ppad)); HIPCHK(c, c->kidx.ensure((size_t)B * c->plan.Ppad)); }
   else HIPCHK(c, c->tablef.ensure((size_t)B * c->K));
   if (c->prm.record_trace) {
@@ -751,7 +751,7 @@ int svnicp_build_candidate_table(svnicp_ctx* c) {
   HIPCHK(c, prof_begin(c, KC_TABLE));
   if (c->plan.f32 == 3)
     HIPCHK(c, launch_build_table3(c->cand_idx.p, c->B, c->K, c->tgt.p, c->M, c->plan.f32 == 3 ? nullptr : c->table.p,
-                                  c->anchor.p, c->tablea.p, c->tail.p, c->cmaxb.p, c->stream));
+                                  c->anchor.p, c->tablea.p, c->cmaxb.p, c->stream));
   else
     HIPCHK(c, launch_build_table2(c->cand_idx.p, c->B, c->K, c->tgt.p, c->M, c->table.p, c->tablef.p, c->cmaxb.p, c->stream));
   HIPCHK(c, prof_end(c));
@@ -811,7 +811,7 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   const int nshard = c->p_hi - c->p_lo;
   if (nshard <= 0) return SVNICP_OK;
   AccumArgs a{};
-  a.src = c->src.p; a.table = c->table.p; a.tablef = c->tablef.p; a.tablea = c->tablea.p; a.kbest = c->kbest.p; a.kidx = c->kidx.p; a.tgt = c->tgt.p; a.cand = c->cand_idx.p; a.anchor = c->anchor.p; a.tail = c->tail.p; a.M = c->M; a.cmax = c->cmaxb.p; a.ambig_count = c->ambig.p;
+  a.src = c->src.p; a.table = c->table.p; a.tablef = c->tablef.p; a.tablea = c->tablea.p; a.kbest = c->kbest.p; a.kidx = c->kidx.p; a.tgt = c->tgt.p; a.cand = c->cand_idx.p; a.anchor = c->anchor.p; a.M = c->M; a.cmax = c->cmaxb.p; a.ambig_count = c->ambig.p;
   a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K;
   a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
   a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;

@@ -143,7 +143,6 @@ struct AccumArgs {
   const double* tgt;    // [M][3]
   const int32_t* cand;  // [B][K] candidate indices (stage A)
   const double* anchor; // [B][3] = tgt[cand[b][0]]
-  const float4* tail;   // [B][4] float32 local rows of candidates 96..99 (K in 97..100: scored by the VALU, see stein_split.hip)
   int64_t M;
   uint8_t* kbest;       // split variant: winner slot per (source point, particle of the shard), [B][Ppad]
   int32_t* kidx;        // … and the winner's TARGET index cand[b][slot], [B][Ppad]: the accumulate kernel's gather then starts one
@@ -180,7 +179,7 @@ hipError_t launch_accumulate_split(const AccumPlan& plan, const AccumArgs& a, hi
 void split_occupancy_blocks(int PW, int WP, int K, size_t smem, int* search, int* accum);
 // table may be nullptr (split variant): then only anchor / tablea / cmax are written
 hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
-                               double* anchor, float4* tablea, float4* tail, float* cmax, hipStream_t st);
+                               double* anchor, float4* tablea, float* cmax, hipStream_t st);
 hipError_t launch_build_table2(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
                                float4* tablef, float* cmax, hipStream_t st);
 // q[b] = (s·R^T) + t with the stage-B expression (SVNICP.cpp:62-64); pose12 = device [R row-major | t]

@@ -587,8 +587,9 @@ AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f3
     if (tune.wgpcu_search >= 1 && tune.wgpcu_search <= 64 && tune.wgpcu_accum >= 1 && tune.wgpcu_accum <= 16) {
       occ_s = tune.wgpcu_search; occ_a = tune.wgpcu_accum;   // profiling knob
     } else {  // measured at C3: the barrier-free search kernel balances best with about four rounds of smaller workgroups
-      occ_s *= (PW == 64 ? 4 : 2);       // (4.65 ms per registration at two rounds, 4.55 at four to twelve, 4.73 at sixteen;
-                                         // with fewer than 64 particles per group — C2 — two rounds stay ahead: 0.94 vs 1.01 ms);
+      if (PW == 64) occ_s *= 4;          // (round 3, tile tracking: 4.03 ms per registration at two rounds, 3.91 at four, 4.10 at six and eight);
+                                         // with fewer than 64 particles per group — C2 — ONE round: 1.03 ms against 1.18 at two and
+                                         // 1.31 at four (every workgroup pays its pose prologue and its exact-pass epilogue);
                                          // the accumulate kernel pays per workgroup in k_reduce_partials: 4 per CU
       if (occ_a > 4) occ_a = 4;
     }

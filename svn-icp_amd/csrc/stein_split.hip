@@ -201,7 +201,8 @@ template <int PW, int WP, int NRB, bool TAIL>
 #ifndef SVNICP_SEARCH_WAVES
 #define SVNICP_SEARCH_WAVES 4
 #endif
-__global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(AccumArgs a) {
+// (16-particle groups hold four points' rows in LDS, 256-particle workgroups four groups' poses: three workgroups per CU)
+__global__ __launch_bounds__(NT, (PW == 16 || WP == 4) ? 3 : SVNICP_SEARCH_WAVES) void k_stein_search_bf16(AccumArgs a) {
   if (a.ctl[0]) return;
   constexpr int BW = kWave / PW;   // source points per wave step (1, 2, 4)
   constexpr int CBP = PW / 16;     // 16-particle column blocks per source point (4, 2, 1)
@@ -233,9 +234,7 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
   const SVNICP_CONST_AS double* csrc = (const SVNICP_CONST_AS double*)a.src;
   const SVNICP_CONST_AS double* canc = (const SVNICP_CONST_AS double*)a.anchor;
   const SVNICP_CONST_AS float* ccmax = (const SVNICP_CONST_AS float*)a.cmax;
-  const SVNICP_CONST_AS v4f* ctail = (const SVNICP_CONST_AS v4f*)a.tail;
   const SVNICP_CONST_AS v4f* ctab = (const SVNICP_CONST_AS v4f*)a.tablea;
-  const v4f* gtail = reinterpret_cast<const v4f*>(a.tail);
   // LDS copy of a point's rows, written from the A-operand registers: lane (mj, mk) holds component mk of candidates
   // 16·rb + mj — one 4-byte store per row block
   float* const rows_w = reinterpret_cast<float*>(&s_rows[wave][0][mj & 3][mj >> 2]) + mk;
@@ -247,24 +246,58 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
   int pend_idx = 0;       // winner's target index of the previous step, stored one step late (see the end of the step)
   size_t pend_off = 0;
   bool pend_have = false;
-  v4f alo_n, ahi_n, tl_n = {0.f, 0.f, 0.f, 0.f};   // PIPE: table rows of the NEXT step, in flight while this step's tiles run
+  v4f alo_n, ahi_n;   // PIPE: table rows of the NEXT step, in flight while this step's tiles run
+  // … and the next point's source row, local origin and C2 — as VECTOR loads (lanes 0-2, 3-5: one double each; every lane:
+  // C2).  As scalar loads at the top of the step they were waited for at once, and the tail rows' scalar loads of every
+  // group step held up the next LDS wait (scalar loads and LDS share one counter): three exposed L2 round trips per point.
+  double sa_n = 0.0;
+  float c_n = 0.0f;
+  auto fetch_point = [&](int64_t nn) {
+    const double* base = lane < 3 ? a.src + 3 * nn : a.anchor + 3 * nn - 3;
+    sa_n = base[lane < 6 ? lane : 3];
+    c_n = a.cmax[nn];
+  };
+  // several points per step (PW < 64): the rows of ALL the next step's points, requested at the top of this step (requested
+  // where they are used, each point's two row loads were an exposed round trip: C2's search ran at 2.4x C3's time per pair)
+  // (one buffer per point: a point's registers are free once its rows are split, and are refilled at once)
+  v4f ralo_n[PIPE ? 1 : NPT], rahi_n[PIPE ? 1 : NPT];
+  auto fetch_rows = [&](int64_t n0, int pt) {
+    int64_t bq = n0 + pt;
+    bq = bq < blk_hi ? bq : (n0 < blk_hi ? n0 : blk_lo);
+    const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)bq * 128 + lane;
+    ralo_n[pt] = rowp[0];
+    rahi_n[pt] = ralo_n[pt];
+    if constexpr (NRB > 4) rahi_n[pt] = rowp[64];
+  };
+  if constexpr (!PIPE) {
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) fetch_rows(nfirst, pt);
+  }
   if constexpr (PIPE) {
+    fetch_point(nfirst < blk_hi ? nfirst : blk_lo);
     const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)(nfirst < blk_hi ? nfirst : blk_lo) * 128 + lane;
     alo_n = rowp[0];
     ahi_n = alo_n;
     if constexpr (NRB > 4) ahi_n = rowp[64];
-    if constexpr (TAIL) tl_n = gtail[(size_t)(nfirst < blk_hi ? nfirst : blk_lo) * 4 + (lane & 3)];
   }
 
   for (int64_t n = nfirst; n < blk_hi; n += ST) {  // wave-uniform
     const int64_t b = n + bs;
     const bool inb = b < blk_hi;
     const int64_t bl = inb ? b : n;
-    const SVNICP_CONST_AS double* sp = csrc + 3 * bl;
-    const SVNICP_CONST_AS double* an = canc + 3 * bl;               // first candidate = origin of the local frame
-    const double s0 = sp[0], s1 = sp[1], s2 = sp[2];
-    const double a0 = an[0], a1 = an[1], a2 = an[2];
-    const float C = ccmax[bl];
+    double s0, s1, s2, a0, a1, a2;   // source row; first candidate = origin of the local frame
+    float C;
+    if constexpr (PIPE) {
+      s0 = rdlane_f64(sa_n, 0); s1 = rdlane_f64(sa_n, 1); s2 = rdlane_f64(sa_n, 2);
+      a0 = rdlane_f64(sa_n, 3); a1 = rdlane_f64(sa_n, 4); a2 = rdlane_f64(sa_n, 5);
+      C = __uint_as_float((unsigned int)__builtin_amdgcn_readfirstlane((int)__float_as_uint(c_n)));
+    } else {
+      const SVNICP_CONST_AS double* sp = csrc + 3 * bl;
+      const SVNICP_CONST_AS double* an = canc + 3 * bl;
+      s0 = sp[0]; s1 = sp[1]; s2 = sp[2];
+      a0 = an[0]; a1 = an[1]; a2 = an[2];
+      C = ccmax[bl];
+    }
 
     // the A operands of a point: its table rows split into bf16 pieces.  One point per step (PW = 64): split once here and
     // used by every particle group; several points per step (PW < 64, one particle group): split when the column blocks reach
@@ -278,19 +311,21 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
         afr[rb] = split_a3(v);
         rows_w[(pt * 4 * NTILE + 4 * rb) * 4] = v;   // row 16·rb + mj lives at [(mj & 3)][4·rb + (mj >> 2)]
       }
+      if constexpr (TAIL) {   // candidates 16·NRB … +3 sit in row block NRB of the table (lanes mj < 4): the tile the owner lanes score
+        const float v = NRB == 4 ? ahi.x : NRB == 5 ? ahi.y : NRB == 6 ? ahi.z : ahi.w;
+        if (mj < 4) rows_w[(pt * 4 * NTILE + 4 * NRB) * 4] = v;
+      }
     };
     if constexpr (PIPE) {
       const v4f alo = alo_n, ahi = ahi_n;
-      const v4f tlc = tl_n;
       int64_t nn = n + ST;
       nn = nn < blk_hi ? nn : n;
       const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)nn * 128 + lane;
       alo_n = rowp[0];
       if constexpr (NRB > 4) ahi_n = rowp[64];
-      if constexpr (TAIL) tl_n = gtail[(size_t)nn * 4 + (lane & 3)];
+      fetch_point(nn);
       __builtin_amdgcn_wave_barrier();   // the previous step's tile reads are done
       split_rows(alo, ahi, 0);
-      if constexpr (TAIL) { if (lane < 4) *reinterpret_cast<v4f*>(&s_rows[wave][0][lane][4 * NRB]) = tlc; }   // rows 16·NRB + lane
     }
 
 #pragma nounroll
@@ -321,14 +356,8 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
       for (int cb = 0; cb < 4; ++cb) {
         if constexpr (!PIPE) {
           if (cb % CBP == 0) {
-            int64_t bq = n + cb / CBP;
-            bq = bq < blk_hi ? bq : n;
-            const SVNICP_CONST_AS v4f* rowp = ctab + (size_t)bq * 128 + lane;
-            const v4f alo = rowp[0];
-            v4f ahi = alo;
-            if constexpr (NRB > 4) ahi = rowp[64];
-            split_rows(alo, ahi, cb / CBP);
-            if constexpr (TAIL) { if (lane < 4) *reinterpret_cast<v4f*>(&s_rows[wave][cb / CBP][lane][4 * NRB]) = gtail[(size_t)bq * 4 + lane]; }
+            split_rows(ralo_n[cb / CBP], rahi_n[cb / CBP], cb / CBP);
+            fetch_rows(n + ST, cb / CBP);
           }
         }
         const bf8 bfr = split_b3(braw[cb]);
@@ -398,11 +427,11 @@ __global__ __launch_bounds__(NT, SVNICP_SEARCH_WAVES) void k_stein_search_bf16(A
         merge2(__uint_as_float(r1[0]), __uint_as_float(r1[1]), __uint_as_float(r2[0]), __uint_as_float(r2[1]), b1own, b2own);
       }
       if constexpr (TAIL) {   // candidates 16·NRB … +3: one more tile (row block NRB of lane group 0), scored by the owner lane
-        const SVNICP_CONST_AS v4f* tl = ctail + (size_t)bl * 4;
+        const float4* tl = &s_rows[wave][bs][0][4 * NRB];   // rows 16·NRB + t at [t][4·NRB]: the same address in every lane (broadcast)
         float sc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const v4f c = tl[t];  // (c'x, c'y, c'z, |c'|²), a finite sentinel past K
+          const float4 c = tl[t * NTILE];  // (c'x, c'y, c'z, |c'|²), a finite sentinel past K
           sc[t] = __builtin_fmaf(c.x, mm0, __builtin_fmaf(c.y, mm1, __builtin_fmaf(c.z, mm2, c.w)));
         }
         const float pk = pack_slot(fmin_raw(fmin3_raw(sc[0], sc[1], sc[2]), sc[3]), 0x1fu, (unsigned int)NRB);
@@ -671,14 +700,14 @@ __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulat
 // ---------------------------------------------------------------------------------------------
 // candidate table of the search kernel: one wave per source point.  Candidates relative to the point's first candidate as
 // float32 (c'x, c'y, c'z, |c'|²) in MFMA A-operand order (lane = 16·component + candidate mod 16, one float4 per four 16-row
-// blocks; rows past K are finite sentinels), the origin of the local frame, C_b = max |c'|₂ rounded up (the error bound's
-// C2) and candidates 96…99 (the tile the owner lanes score themselves when K is 97…100).  Replaces the I copies of target_batch [B,K,3] of SVGDICP.cpp:191-198.
+// blocks; rows past K are finite sentinels), the origin of the local frame and C_b = max |c'|₂ rounded up (the error
+// bound's C2).  (Candidates 96…99 — the tile the owner lanes score themselves when K is 97…100 — are row block 6 like any other.)  Replaces the I copies of target_batch [B,K,3] of SVGDICP.cpp:191-198.
 // ---------------------------------------------------------------------------------------------
 constexpr float kSentinelCC = 1.0e30f; // padded rows: finite, so packed words never become NaN patterns
 __global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict__ idx, int64_t B, int K,
                                                       const double* __restrict__ tgt, int64_t M, double* __restrict__ table,
                                                       double* __restrict__ anchor, float4* __restrict__ tablea,
-                                                      float4* __restrict__ tail, float* __restrict__ cmax) {
+                                                      float* __restrict__ cmax) {
   __shared__ float rowbuf[4][128 * 4];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + wave;
@@ -716,7 +745,6 @@ __global__ __launch_bounds__(256) void k_build_table3(const int32_t* __restrict_
     anchor[3 * b] = a0; anchor[3 * b + 1] = a1; anchor[3 * b + 2] = a2;
   }
   __builtin_amdgcn_wave_barrier();
-  if (tail && lane < 4) tail[(size_t)b * 4 + lane] = make_float4(rb[4 * (96 + lane)], rb[4 * (96 + lane) + 1], rb[4 * (96 + lane) + 2], rb[4 * (96 + lane) + 3]);
   const int mi = lane & 15, mk = lane >> 4;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -796,10 +824,10 @@ void split_occupancy_blocks(int PW, int WP, int K, size_t smem, int* search, int
 }
 
 hipError_t launch_build_table3(const int32_t* idx, int64_t B, int K, const double* tgt, int64_t M, double* table,
-                               double* anchor, float4* tablea, float4* tail, float* cmax, hipStream_t st) {
+                               double* anchor, float4* tablea, float* cmax, hipStream_t st) {
   if (B <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_build_table3, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, idx, B, K, tgt, M, table, anchor, tablea,
-                     tail, cmax);
+                     cmax);
   return hipGetLastError();
 }
 

@@ -31,6 +31,8 @@ __device__ __forceinline__ void accumulate_point(const Pending& pd, const double
     w = wq * wq;                                        // SVNICP.cpp:122
     e0 = w * dx; e1 = w * dy; e2 = w * dz;              // SVNICP.cpp:119,123
     n0 = spts[3 * pd.pt]; n1 = spts[3 * pd.pt + 1]; n2 = spts[3 * pd.pt + 2];
+  } else if (best != best) {   // masking is a multiplication in the reference (SVGDICP.cpp:331-333): a NaN row stays NaN
+    w = best; e0 = best; e1 = best; e2 = best;
   }
   const double w0 = w * n0, w1 = w * n1, w2 = w * n2;
   acc[0] += w;

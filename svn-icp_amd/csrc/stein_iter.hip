@@ -147,6 +147,10 @@ __global__ __launch_bounds__(NT) void k_icp_single(AccumArgs a, UpdateArgs u) {
       w = wq * wq;                                      // SVNICP.cpp:122
       e0 = w * dx; e1 = w * dy; e2 = w * dz;            // SVNICP.cpp:119,123
       m0 = s0; m1 = s1; m2 = s2;
+    } else if (best != best) {
+      // the reference masks by MULTIPLYING the rows with 0 / 1 (SVGDICP.cpp:331-333): a non-finite row (a particle whose pose
+      // went NaN) stays NaN, and so does every sum it enters — k_stein_accumulate_w forms the same products
+      w = best; e0 = best; e1 = best; e2 = best;
     }
     const double w0 = w * m0, w1 = w * m1, w2 = w * m2;
     acc[0] = w;
@@ -259,6 +263,8 @@ __global__ __launch_bounds__(NT) void k_stein_accumulate(AccumArgs a, UpdateArgs
           e1 = w * (T1 - row[3 * kb + 1]);
           e2 = w * (T2 - row[3 * kb + 2]);
           m0 = s0; m1 = s1; m2 = s2;
+        } else if (best != best) {   // masking is a multiplication in the reference: a NaN row stays NaN (see k_icp_single)
+          w = best; e0 = best; e1 = best; e2 = best;
         }
         const double w0 = w * m0, w1 = w * m1, w2 = w * m2;
         acc[0] += w;

@@ -587,6 +587,34 @@ def test_small_chain_equals_general_chain(hip, orc, P, full, mode):
     assert np.allclose(out["auto"][0], out["general"][0], rtol=0, atol=1e-10)
 
 
+def test_two_particles_zero_bandwidth_goes_nan_like_the_reference(hip, orc):
+    """Two particles: the lower median of the four pair distances {0, 0, d, d} is 0, the RBF bandwidth is 0 and the first
+    Stein step is NaN (SVNICP.cpp:262, 218-252).  From then on the reference's masking BY MULTIPLICATION (SVGDICP.cpp:331-333)
+    keeps every row of a NaN particle NaN, so H and b are NaN too — also in the kernels that serve up to eight particles,
+    which mask with a branch and must poison the sums explicitly."""
+    P, B, M, K, I = 2, 1100, 9000, 50, 4
+    src, tgt = hip.scans.random_clouds(B, M, seed=P + 7, extent=20.0)
+    init = hip.scans.make_particles(P, seed=P) * 0.2
+    cfg = dict(iterations=I, lr=1.0, max_dist=1.0, check_early_stop=False, convergence_threshold=1e-5, knn_count=K, svn_full_grad=False)
+    o = orc.Solver(init, **cfg); o.add_cloud(src, tgt, init); tro = o.enable_trace(); o.stein_align()
+    for accum in ("valu", "f64"):
+        s = _hip_solver(hip, init, **cfg); s.set_option("accum", accum); s.add_cloud(src, tgt, init)
+        assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+        tr = s.get_trace()
+        assert np.isnan(tro["H"][1:]).all() and np.isfinite(tro["H"][0]).all()
+        for key in ("b", "phi"):
+            assert np.array_equal(np.isnan(tr[key]), np.isnan(tro[key])), (accum, key)
+            assert np.allclose(tr[key], tro[key], rtol=1e-9, atol=1e-9, equal_nan=True), (accum, key)
+        # H is assembled from the 22 raw sums: its structural zeros (and the 1e-6 on the rotation block's diagonal where the
+        # sums cancel) stay numbers where the reference's literal JᵀwJ gives NaN·0 = NaN; everything fed by a sum is NaN
+        hn, on = np.isnan(tr["H"]), np.isnan(tro["H"])
+        assert not (hn & ~on).any() and hn[1:].reshape(I - 1, P, 36)[:, :, 0].all()
+        assert np.allclose(tr["H"][0], tro["H"][0], rtol=1e-11, atol=1e-9)
+        # (the rotation entries are 0, not NaN: rotm_to_ypr_tensor fills them where |sin| > 1e-12 fails, SVNICP.cpp:205-213)
+        assert np.array_equal(np.isnan(s.get_particles()), np.isnan(o.get_particles())) and np.isnan(s.get_particles()).any()
+        assert np.allclose(s.get_particles(), o.get_particles(), equal_nan=True)
+
+
 # ------------------------------------------------------------------ split-phase ABI (multi-GPU path) on one GPU
 def test_split_phase_two_shards_equal_single_context(hip):
     """Two contexts on one GPU play two ranks: particle shards [0,P/2) and [P/2,P), candidate rows

@@ -282,9 +282,11 @@ def main():
             out["roofline"] = {"kernel": "k_stein_search_bf16", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF,
                                "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF, "traffic": tr,
                                "executed_bf16_TFLOPs": mfma_exec_tf, "executed_frac_of_bf16_peak": mfma_exec_tf / BF16_MFMA_PEAK_TF,
-                               "note": "nearest-of-K scores on v_mfma_f32_16x16x32_bf16 (exact bf16x3 splits) + 2.3 VALU "
-                                       "instructions per score (slot packing, min3/med3 triples); the kernel is bound by vector-instruction issue (one "
-                                       "instruction per ~4 cycles per SIMD, PMC in profiles/), not by the matrix pipe or "
+                               "note": "nearest-of-K scores on v_mfma_f32_16x16x32_bf16 (exact bf16x3 splits) + about one VALU "
+                                       "instruction per score to track them (minimum of each 4-candidate tile, smallest and second smallest "
+                                       "tagged tile minimum; the winning tile re-scored by the owner lane); the kernel is bound by "
+                                       "vector-instruction issue (3.5 vector instructions per score in all, the vector unit ~80 % busy: PMC in "
+                                       "profiles/), not by the matrix pipe or "
                                        "HBM; roofline_hbm is the HBM view; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE "
                                        "per launch (profiles/traffic.json)"}
             out["roofline_hbm"] = hbm

@@ -27,7 +27,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline  — the CPU oracle ("port": oracle/svnicp_oracle.c, OpenMP) timed on this box's host
                   cores on the same workload (rank 0, N = 1 only),
   svn_full_grad — the same registration with SVNFullGrad = true (BASELINE.md §2 reports both branches),
-  svgd_adam     — SVGD-ICP (Adam, lr 0.01) on the same clouds; c4_one_gpu — 512 particles on one GPU.
+  svgd_adam     — SVGD-ICP (Adam, lr 0.01) on the same clouds; c4_one_gpu — 512 particles on one GPU;
+  other_configs — wall time of whole registrations at C1, C2 and at the size the scan-to-map loop hands to the solver.
 The timed region carries no profiling hooks; the roofline block comes from a second pass over the same K steps with
 every kernel launch bracketed by hipEvents on the library's stream.
 """
@@ -325,6 +326,34 @@ def main():
         out["c4_one_gpu"] = {"workload": f"C4 on one GPU: {c4['P']} particles, C3 clouds", "registrations_per_s": nside / e4,
                              "ms_per_step": 1e3 * e4 / nside}
         s4.close()
+        # the other one-GPU configurations of BASELINE.json and the size the reference's scan-to-map loop hands to the solver
+        # (OdometryPipeline.cpp:559-560: ~1 100 source points after the two samplings, a ~50 000-point local map): wall time
+        # of whole registrations, clouds resident in HBM, like the headline
+        other = {}
+        def side(name, workload, Po, src_np, tgt_np, n):
+            sd, td = torch.from_numpy(src_np).to(dev), torch.from_numpy(tgt_np).to(dev)
+            init_o = scans.make_particles(Po)
+            so = pkg.SVNICP(prm, init_o, pkg.ParticleWeightOpt(), device=local_rank)
+            def st():
+                so.add_cloud(sd, td, init_o); so.set_initial_mean(T0)
+                return so.stein_align(), so.get_transformation(), so.get_cov_matrix()
+            for _ in range(3): st()
+            eo = time_steps(st, n, 1, dist, torch, dev)
+            other[name] = {"workload": workload, "registrations_per_s": n / eo, "ms_per_step": 1e3 * eo / n}
+            so.close()
+        for cname in ("C1", "C2"):
+            cc = scans.CONFIGS[cname]
+            pr = scans.make_pair(cc["B"], cc["M"])
+            side(cname.lower(), f"{cname}: {cc['P']} particle(s), {cc['B']}-pt source vs {cc['M']}-pt target, K={K}, I={I}", cc["P"],
+                 pr.source, pr.target, 20)
+        from svnicp_amd.pipeline import downsample_uniform, crop_pointcloud
+        pr = scans.make_pair(65536, 50000)
+        srcc, _ = crop_pointcloud(pr.source, 1.0, 100.0)
+        small = downsample_uniform(downsample_uniform(srcc, 0.5), 1.5)
+        for Po in (128, 30):
+            side(f"scan_to_map_size_p{Po}", f"{Po} particles, {small.shape[0]}-pt source (a 65536-pt scan after the loop's two uniform samplings) "
+                 f"vs 50000-pt local map, K={K}, I={I}", Po, small, pr.target, 40)
+        out["other_configs"] = other
         from svnicp_amd.sharded import ShardedSVNICP
         ss = ShardedSVNICP(prm, init, device_index=local_rank)
         sst = make_step(ss, init); sst()

@@ -28,7 +28,12 @@ for c in range(n_cases):
     init = hip.scans.make_particles(P, seed=seed + 1) * (0.2 * scale)
     cfg = dict(iterations=1, lr=1.0, max_dist=(1.0 if kind != "tiny" else 1e-6), knn_count=K, svn_full_grad=bool(seed & 1))
     o = orc.Solver(init, **cfg); o.add_cloud(src, tgt, init); tro = o.enable_trace(); o.stein_align()
-    s = _hip_solver(hip, init, **cfg); s.add_cloud(src, tgt, init); s.stein_align()
+    s = _hip_solver(hip, init, **cfg)
+    if seed % 2:
+        s.set_option("knn", "tiles")        # every other case: the Morton-tile stage A where the size would choose the brute-force kernel
+    if seed % 4 >= 2:
+        s.set_option("chain", "general")    # and half of them the general launch chain
+    s.add_cloud(src, tgt, init); s.stein_align()
     tr = s.get_trace()
     ok = (np.array_equal(s.get_candidates().astype(np.int64), o.candidates()) and np.array_equal(s.get_candidate_dist2(), o.candidate_dist2())
           and np.array_equal(tr["corr"][:1], tro["corr"][:1])

@@ -385,6 +385,30 @@ def main():
         if Bs == B:
             out["cpu_baseline"]["max_abs_pose_diff_vs_gpu"] = float(np.abs(op - mean).max())
 
+    if rank == 0 and world == 1 and a.cpu_sample != 0 and not svgd and wl == "C3":
+        # BASELINE.json configs[0] is "the reference CPU path": the reference's solver is a libtorch tensor program, and
+        # oracle/torch_restatement.py replays it op for op through the same ATen kernels (einsum / bmm / linalg_solve / median
+        # on CPU, float64).  Timed here at C1 on this box's host cores beside the GPU's C1 registration (bounded: ~1-3 s).
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import torch_restatement as tre
+        c1 = scans.CONFIGS["C1"]
+        pr1 = scans.make_pair(c1["B"], c1["M"])
+        init1 = scans.make_particles(c1["P"])
+        tp = tre.SteinICPParam(iterations=I, lr=prm.lr, max_dist=1.0, check_early_stop=False, KNN_count=K, SVN_full_grad=False)
+        ts = tre.SVNICP(tp, torch.from_numpy(init1))
+        ts.add_cloud(torch.from_numpy(pr1.source), torch.from_numpy(pr1.target), torch.from_numpy(init1))
+        ts.set_initial_mean(np.eye(3), np.zeros(3))
+        t1 = time.perf_counter()
+        ts.stein_align()
+        tl = time.perf_counter() - t1
+        g1 = pkg.SVNICP(prm, init1, pkg.ParticleWeightOpt(), device=local_rank)
+        g1.add_cloud(pr1.source, pr1.target, init1); g1.set_initial_mean(T0); g1.stein_align()
+        out["cpu_baseline_libtorch_c1"] = {"value": 1.0 / tl, "unit": "registrations/s", "cores": torch.get_num_threads(), "kind": "port",
+                                           "sample": f"oracle/torch_restatement.py (the reference's tensor program op for op on libtorch CPU, f64) at C1: "
+                                                     f"1 particle, {c1['B']}-pt source vs {c1['M']}-pt target, K={K}, I={I}: {tl:.2f} s",
+                                           "max_abs_pose_diff_vs_gpu": float(np.abs(ts.get_transformation().numpy() - g1.get_transformation()).max())}
+        g1.close()
+
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

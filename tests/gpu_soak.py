@@ -22,7 +22,7 @@ for c in range(n_cases):
     big = rng.random() < 0.4                      # Morton tiles need >= 8192 padded targets
     B = int(rng.integers(200, 4000)); M = int(rng.integers(9000, 40000) if big else rng.integers(600, 9000))
     K = int(rng.choice([1, 5, 16, 17, 50, 96, 97, 100, 128]))
-    P = int(rng.choice([2, 9, 16, 33, 64, 96, 128, 130, 200]))
+    P = int(rng.choice([1, 2, 9, 16, 30, 33, 64, 96, 128, 130, 200]))
     src, tgt = _fuzz_cloud(kind, rng, B, M)
     scale = 1e-3 if kind == "tiny" else 1.0
     init = hip.scans.make_particles(P, seed=seed + 1) * (0.2 * scale)

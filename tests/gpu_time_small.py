@@ -5,6 +5,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
+if os.environ.get("SVNICP_TEST_LIB"):   # A/B builds of the library (bring-up only)
+    pkg.binding._LIB_PATH = os.path.abspath(os.environ["SVNICP_TEST_LIB"])
 import torch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 50000

@@ -73,6 +73,8 @@ struct svnicp_ctx {
   DevBuf<int32_t> pool_i, cand_idx, trcorr, torig, pool2, fail_list;
   DevBuf<float> txf, tyf, tzf, cmaxb;
   DevBuf<float4> tablef, tablea;
+  DevBuf<unsigned int> small_bar;   // persistent small-registration kernel: arrivals, generation, error word
+  bool small_launched = false;      // the last svnicp_align_async ran the persistent kernel (its error word is checked at the next synchronisation)
   DevBuf<uint8_t> kbest;
   DevBuf<int32_t> kidx;
   // source-row sharding (svnicp_set_row_shard): this context holds rows of a larger scan; its per-iteration sums are one of
@@ -281,10 +283,12 @@ int svnicp_set_stream(svnicp_ctx* c, void* hip_stream) {
   return SVNICP_OK;
 }
 
+static int check_small_kernel(svnicp_ctx* c);
 int svnicp_synchronize(svnicp_ctx* c) {
   CTX_CHECK(c);
   if (bind(c)) return SVNICP_ERR_HIP;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (const int rc = check_small_kernel(c)) return rc;
   if (c->have_result && c->h_stats) c->host_stats_valid = true;   // svnicp_finish's copy of the result block has landed
   return SVNICP_OK;
 }
@@ -420,7 +424,8 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "group_stride") ok = num(0, 1 << 30, &t.group_stride);
   else if (k == "accum_min_steps") ok = num(0, 1 << 20, &t.accum_min_steps);
   else if (k == "single") { if (v == "fused") t.single_fused = 1; else if (v == "split") t.single_fused = 0; else ok = false; }
-  else if (k == "chain") { if (v == "auto") t.small_chain = 1; else if (v == "general") t.small_chain = 0; else ok = false; }
+  else if (k == "chain") { if (v == "auto") { t.small_chain = 1; t.persistent = 0; } else if (v == "persistent") { t.small_chain = 1; t.persistent = 1; }
+                           else if (v == "general") { t.small_chain = 0; t.persistent = 0; } else ok = false; }
   else if (k == "correspondence") { if (v == "fast") t.full_corr = 0; else if (v == "full") t.full_corr = 1; else ok = false; }
   else return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: unknown option '" + k + "'");
   if (!ok) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: bad value '" + v + "' for option '" + k + "'");
@@ -602,6 +607,8 @@ int svnicp_align_begin(svnicp_ctx* c) {
     add(c->history.p, (size_t)(I > 0 ? I : 1) * 6 * P * sizeof(float));
     add(c->ambig.p, 2 * sizeof(int));
     if (c->knn_variant == 3) add(c->fail_count.p, sizeof(int));
+    HIPCHK(c, c->small_bar.ensure(8));
+    add(c->small_bar.p, 8 * sizeof(unsigned int));
     if (c->prm.mode == SVNICP_MODE_SVGD) add(c->opt.p, (size_t)P * 18 * sizeof(double));
     z.ctl = c->ctl.p; z.iterations = I;
     HIPCHK(c, launch_init_particles(c->init_pose.p, P, c->pose0, 2, c->R.p, c->t.p, c->Rtot.p, c->pose_out.p, 0,
@@ -928,11 +935,47 @@ int svnicp_align_async(svnicp_ctx* c) {
   if (rc) return rc;
   if ((rc = svnicp_stage_candidates(c, 0, c->B))) return rc;
   if ((rc = svnicp_build_candidate_table(c))) return rc;
+  c->small_launched = false;
+  if (small_chain(c) && c->tune.persistent && !c->prm.record_trace && !c->profile && c->prm.iterations > 0 &&
+      small_registration_supported(c->plan.PW, c->plan.WP, c->K)) {
+    // all iterations in ONE cooperative launch (particle_update.hip: k_small_registration); anything the runtime refuses
+    // (no cooperative launch, grid not resident) falls back to the four launches per iteration
+    AccumArgs a{};
+    a.src = c->src.p; a.tablea = c->tablea.p; a.kbest = c->kbest.p; a.kidx = c->kidx.p; a.tgt = c->tgt.p; a.cand = c->cand_idx.p;
+    a.anchor = c->anchor.p; a.M = c->M; a.cmax = c->cmaxb.p; a.ambig_count = c->ambig.p;
+    a.Rtot = c->Rtot.p; a.B = c->B; a.K = c->K; a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist;
+    a.partial = c->partial.p; a.ctl = c->ctl.p; a.svgd = c->prm.mode == SVNICP_MODE_SVGD ? 1 : 0;
+    if (c->tune.debug && !c->dbg_upd) { HIPCHK(c, hipMalloc(&c->dbg_upd, 8 * sizeof(unsigned long long))); }
+    if (c->tune.debug) HIPCHK(c, hipMemsetAsync(c->dbg_upd, 0, 8 * sizeof(unsigned long long), c->stream));
+    UpdateArgs u = update_args(c, 0);
+    u.sums_out = c->sums.p;
+    const hipError_t e = launch_small_registration(c->plan, a, u, c->prm.iterations, c->small_bar.p, c->num_cus, c->stream);
+    if (e == hipSuccess && c->tune.debug) {
+      unsigned long long h[8];
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpy(h, c->dbg_upd, sizeof h, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[svnicp] k_small_registration, workgroup 0, cycles over %d iterations: search %llu | barrier %llu | accumulate %llu | barrier %llu | prepare %llu | barrier %llu | direction %llu | barrier %llu\n",
+              c->prm.iterations, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    }
+    if (e == hipSuccess) { c->small_launched = true; return svnicp_finish(c); }
+    (void)hipGetLastError();
+  }
   for (int it = 0; it < c->prm.iterations; ++it) {
     if ((rc = svnicp_iter_accumulate(c, it))) return rc;
     if ((rc = svnicp_iter_update(c, it))) return rc;
   }
   return svnicp_finish(c);
+}
+
+// the persistent kernel's barrier gives up after a bounded wait and says so in its error word
+static int check_small_kernel(svnicp_ctx* c) {
+  if (!c->small_launched) return SVNICP_OK;
+  c->small_launched = false;
+  unsigned int w[2] = {0u, 0u};
+  HIPCHK(c, hipMemcpyAsync(w, c->small_bar.p, sizeof w, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (w[1] != 0u) { c->have_result = false; return fail(c, SVNICP_ERR_HIP, "svnicp_align: the small-registration kernel's grid barrier timed out (chain=persistent is an option; the default launches do not wait on each other)"); }
+  return SVNICP_OK;
 }
 
 int svnicp_align(svnicp_ctx* c) {
@@ -944,6 +987,7 @@ int svnicp_align(svnicp_ctx* c) {
   int rc = svnicp_align_async(c);
   if (rc) return rc;  // negative status, or SVNICP_NO_OPTIMIZER
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if ((rc = check_small_kernel(c))) return rc;
   c->host_stats_valid = c->h_stats != nullptr;
   return SVNICP_ALIGN_SUCCESS;
 }

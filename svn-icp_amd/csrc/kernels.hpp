@@ -171,6 +171,8 @@ struct Tuning {
   int debug = 0;                 // print plans and per-phase cycle counters to stderr
   int single_fused = 1;          // one particle: reduce + Stein step in the accumulate kernel's last workgroup (0: three launches, A/B)
   int small_chain = 1;           // small registrations: no k_reduce_partials, Stein-step front in one launch on the main stream (0: the general chain, A/B)
+  int persistent = 0;            // 1: svnicp_align runs all iterations of a small-chain registration in ONE cooperative launch (k_small_registration;
+                                 // measured SLOWER than the four launches per iteration on this eight-XCD part: off by default, option chain=persistent)
   int full_corr = 0;             // 1: correspondence = full — per-particle exact NN over the whole target (SVGDICP.cpp:274-298)
 };
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune);
@@ -228,6 +230,10 @@ hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_update_median(const UpdateArgs& a, int num_cus, int max_p_one_workgroup, hipStream_t st);
 hipError_t launch_update_prepare(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_update_prepare_median(const UpdateArgs& a, hipStream_t st);   // small chain: both in one launch (2 <= P <= 128)
+// small chain, all iterations in one cooperative launch (particle_update.hip: k_small_registration)
+bool small_registration_supported(int PW, int WP, int K);
+hipError_t launch_small_registration(const AccumPlan& plan, AccumArgs a, const UpdateArgs& u, int iterations, unsigned int* bar,
+                                     int num_cus, hipStream_t st);
 hipError_t launch_update_direction(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles, double* sums, const int* ctl,
                                   hipStream_t st);

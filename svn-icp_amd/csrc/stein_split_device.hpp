@@ -514,7 +514,7 @@ __device__ __forceinline__ void search_body(const AccumArgs& a, int bx, int by) 
 // (16-particle groups hold four points' rows in LDS, 256-particle workgroups four groups' poses: three workgroups per CU)
 template <int PW, int WP, int NRB, bool TAIL>
 __global__ __launch_bounds__(NT, (PW == 16 || WP == 4) ? 3 : SVNICP_SEARCH_WAVES) void k_stein_search_bf16(AccumArgs a) {
-  search_body<PW, WP, NRB, TAIL>(a, (int)blockIdx.x, (int)blockIdx.y);
+  search_body<PW, WP, NRB, TAIL>(a, xcd_block((int)blockIdx.x, (int)gridDim.x), (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -695,7 +695,7 @@ __device__ __forceinline__ void accumulate_body(const AccumArgs& a, int bx, int 
 template <int PW, int WP, bool PLAIN, bool SVGD = false>
 __global__ __launch_bounds__(NT, (PLAIN && SVGD) ? 4 : 3) void k_stein_accumulate_w(AccumArgs a) {
   extern __shared__ __align__(16) double lds[];
-  accumulate_body<PW, WP, PLAIN, SVGD>(a, (int)blockIdx.x, (int)blockIdx.y, lds);
+  accumulate_body<PW, WP, PLAIN, SVGD>(a, xcd_block((int)blockIdx.x, (int)gridDim.x), (int)blockIdx.y, lds);
 }
 
 }  // namespace

@@ -330,6 +330,20 @@ def test_stage_a_fallback_on_pool_overflow(hip, orc, sliced_max, K):
     assert np.array_equal(s.get_candidate_dist2(), od)
 
 
+@pytest.mark.parametrize("B,M,K", [(1, 1, 1), (5, 3, 7), (64, 130, 128), (9, 1025, 16), (300, 2047, 100), (2, 1023, 1), (1000, 1024, 33)])
+def test_stage_a_brute_force_small_shapes(hip, orc, B, M, K):
+    """knn_brute.hip at the edges of its launch geometry: fewer targets than threads (most threads hold no minimum), one
+    query, one target, K above the target count (zero padding), block counts that are not a multiple of four queries."""
+    src, tgt = hip.scans.random_clouds(B, M, seed=B * 7 + M + K, extent=10.0)
+    init = np.zeros((6, 1))
+    s = _hip_solver(hip, init, trace=False, iterations=1, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
+    s.add_cloud(src, tgt, init); s.stein_align()
+    assert s.get_knn_fallbacks() == 0          # the brute-force kernel (it reports no fallbacks; the other kernels would report -1 or a count)
+    oi, od = orc.knn_topk(src, tgt, K)
+    assert np.array_equal(s.get_candidates().astype(np.int64), oi)
+    assert np.array_equal(s.get_candidate_dist2(), od)
+
+
 @pytest.mark.parametrize("K", [1, 7, 50, 128])
 def test_stage_a_brute_force_exact_ties(hip, orc, K):
     """knn_brute.hip's general path: 2000 targets at exactly the same distance put far more than 256 entries below the

@@ -21,8 +21,12 @@ for c in range(n_cases):
     kind = ["grid", "dups", "far", "tiny", "aniso"][seed % 5]
     big = rng.random() < 0.4                      # Morton tiles need >= 8192 padded targets
     B = int(rng.integers(200, 4000)); M = int(rng.integers(9000, 40000) if big else rng.integers(600, 9000))
+    if os.environ.get("SOAK_BIG"):               # larger draws: Morton-tile stage A, several particle groups per wave, 256-particle workgroups
+        B = int(rng.integers(8000, 40000)); M = int(rng.integers(40000, 300000))
     K = int(rng.choice([1, 5, 16, 17, 50, 96, 97, 100, 128]))
     P = int(rng.choice([1, 2, 9, 16, 30, 33, 64, 96, 128, 130, 200]))
+    if os.environ.get("SOAK_BIG"):
+        P = int(rng.choice([16, 32, 64, 100, 128, 200, 256, 512]))
     src, tgt = _fuzz_cloud(kind, rng, B, M)
     scale = 1e-3 if kind == "tiny" else 1.0
     init = hip.scans.make_particles(P, seed=seed + 1) * (0.2 * scale)

@@ -65,13 +65,9 @@ __device__ __forceinline__ float imax_f(float a, float b) {
 // below one ulp, graded magnitudes with alternating signs, cancelling pairs, 40 binades of exponents, every rotation over
 // the slots) and fails when any result is off by more than HALF of (iii)'s budget — a matrix pipe that behaved worse than
 // every model above would be noticed, not trusted.
-// Packing the slot into the low 7 mantissa bits moves a score by < 127 ulp < 2^-16·|S|.  With b1, b2 the smallest and
-// second smallest PACKED scores, every other candidate's unpacked score is >= b2 − 2^-16|b2| and the winner's is
-// <= b1 + 2^-16|b1|; so if
-//   b2 − b1 > 2·EPS + 2^-16·(1 + 2^-8)·(|b1| + |b2|)
-// every other candidate is strictly farther in exact arithmetic and the packed argmin is the f64 argmin; ties, padded
-// duplicates, NaN/Inf never pass and go to the exact f64 pass.  Tracking: slot packing is v_bitop3_b32 (full-rate VALU
-// class; v_and_or_b32, v_min_*, v_med3_* issue at 0.6x).
+// How EPS is used — the decision between 4-candidate tiles and inside the winning tile, conditions (a) and (b) — is
+// written above search_body.  Ties, padded duplicates, NaN/Inf never pass and go to the exact f64 pass.  Tracking: tags
+// are v_bitop3_b32 (full-rate VALU class; v_and_or_b32, v_min*, v_med3_* issue at 0.6x).
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
@@ -221,9 +217,6 @@ __device__ __forceinline__ void search_body(const AccumArgs& a, int bx, int by) 
     for (int i = 0; i < 12; ++i) s_pose[g][i][lane] = rp[i];
   }
   const int K = a.K;
-  const SVNICP_CONST_AS double* csrc = (const SVNICP_CONST_AS double*)a.src;
-  const SVNICP_CONST_AS double* canc = (const SVNICP_CONST_AS double*)a.anchor;
-  const SVNICP_CONST_AS float* ccmax = (const SVNICP_CONST_AS float*)a.cmax;
   const SVNICP_CONST_AS v4f* ctab = (const SVNICP_CONST_AS v4f*)a.tablea;
   // LDS copy of a point's rows, written from the A-operand registers: lane (mj, mk) holds component mk of candidates
   // 16·rb + mj — one 4-byte store per row block
@@ -274,19 +267,19 @@ __device__ __forceinline__ void search_body(const AccumArgs& a, int bx, int by) 
   for (int64_t n = nfirst; n < blk_hi; n += ST) {  // wave-uniform
     const int64_t b = n + bs;
     const bool inb = b < blk_hi;
-    const int64_t bl = inb ? b : n;
     double s0, s1, s2, a0, a1, a2;   // source row; first candidate = origin of the local frame
     float C;
     if constexpr (PIPE) {
       s0 = rdlane_f64(sa_n, 0); s1 = rdlane_f64(sa_n, 1); s2 = rdlane_f64(sa_n, 2);
       a0 = rdlane_f64(sa_n, 3); a1 = rdlane_f64(sa_n, 4); a2 = rdlane_f64(sa_n, 5);
       C = __uint_as_float((unsigned int)__builtin_amdgcn_readfirstlane((int)__float_as_uint(c_n)));
-    } else {
-      const SVNICP_CONST_AS double* sp = csrc + 3 * bl;
-      const SVNICP_CONST_AS double* an = canc + 3 * bl;
+    } else {   // several points per step: each lane's own point
+      const int64_t bl = inb ? b : n;
+      const double* sp = a.src + 3 * bl;
+      const double* an = a.anchor + 3 * bl;
       s0 = sp[0]; s1 = sp[1]; s2 = sp[2];
       a0 = an[0]; a1 = an[1]; a2 = an[2];
-      C = ccmax[bl];
+      C = a.cmax[bl];
     }
 
     // the A operands of a point: its table rows split into bf16 pieces.  One point per step (PW = 64): split once here and

@@ -330,16 +330,18 @@ def main():
         # (OdometryPipeline.cpp:559-560: ~1 100 source points after the two samplings, a ~50 000-point local map): wall time
         # of whole registrations, clouds resident in HBM, like the headline
         other = {}
-        def side(name, workload, Po, src_np, tgt_np, n):
+        def side(name, workload, Po, src_np, tgt_np, n, param=None):
             sd, td = torch.from_numpy(src_np).to(dev), torch.from_numpy(tgt_np).to(dev)
             init_o = scans.make_particles(Po)
-            so = pkg.SVNICP(prm, init_o, pkg.ParticleWeightOpt(), device=local_rank)
+            so = pkg.SVNICP(param or prm, init_o, pkg.ParticleWeightOpt(), device=local_rank)
             def st():
                 so.add_cloud(sd, td, init_o); so.set_initial_mean(T0)
                 return so.stein_align(), so.get_transformation(), so.get_cov_matrix()
             for _ in range(3): st()
             eo = time_steps(st, n, 1, dist, torch, dev)
             other[name] = {"workload": workload, "registrations_per_s": n / eo, "ms_per_step": 1e3 * eo / n}
+            if param is not None:
+                other[name]["iterations_run"] = int(so.get_iterations_run())
             so.close()
         for cname in ("C1", "C2"):
             cc = scans.CONFIGS[cname]
@@ -353,6 +355,11 @@ def main():
         for Po in (128, 30):
             side(f"scan_to_map_size_p{Po}", f"{Po} particles, {small.shape[0]}-pt source (a 65536-pt scan after the loop's two uniform samplings) "
                  f"vs 50000-pt local map, K={K}, I={I}", Po, small, pr.target, 40)
+        # the reference's shipped solver settings (config/geodeAlpha.yaml): 100 iterations, early stop at 5e-4, 10 particles, max_dist 3
+        shipped = pkg.SteinICPParam(iterations=100, lr=1.0, max_dist=3.0, KNN_count=K, SVN_full_grad=False, check_early_stop=True,
+                                    convergence_threshold=5e-4)
+        side("scan_to_map_size_shipped_p10", f"config/geodeAlpha.yaml solver settings: 10 particles, up to 100 iterations with early stop at 5e-4, "
+             f"max_dist 3, K={K}; {small.shape[0]}-pt source vs 50000-pt local map", 10, small, pr.target, 40, shipped)
         out["other_configs"] = other
         from svnicp_amd.sharded import ShardedSVNICP
         ss = ShardedSVNICP(prm, init, device_index=local_rank)

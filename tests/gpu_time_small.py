@@ -19,6 +19,8 @@ src_ds = downsample_uniform(downsample_uniform(srcc, 0.5 * vox), 1.5 * vox)     
 print("source after the two samplings:", src_ds.shape[0], "points")
 pair.source = src_ds; B = src_ds.shape[0]
 prm = pkg.SteinICPParam(iterations=20, lr=1.0, max_dist=1.0, KNN_count=100, SVN_full_grad=False)
+if os.environ.get("SHIPPED"):   # the reference's shipped solver settings (config/geodeAlpha.yaml: 100 iterations with early stop at 5e-4, max_dist 3)
+    prm = pkg.SteinICPParam(iterations=100, lr=1.0, max_dist=3.0, KNN_count=100, SVN_full_grad=False, check_early_stop=True, convergence_threshold=5e-4)
 s = pkg.SVNICP(prm, init)
 src = torch.from_numpy(pair.source).cuda(); tgt = torch.from_numpy(pair.target).cuda()
 def step():
@@ -29,4 +31,4 @@ n = 20
 for _ in range(n): step()
 torch.cuda.synchronize(); t1 = time.perf_counter()
 s.set_profile(True); step()
-print("B %d M %d P %d: %.3f ms per registration wall; kernel classes (ms):" % (B, M, P, 1e3 * (t1 - t0) / n), {k: round(v[0], 3) for k, v in s.get_kernel_ms().items()}, "GPU span", s.get_gpu_ms().round(3), "ambiguous wave-steps", s.get_ambiguous_steps())
+print("B %d M %d P %d: %.3f ms per registration wall; kernel classes (ms):" % (B, M, P, 1e3 * (t1 - t0) / n), {k: round(v[0], 3) for k, v in s.get_kernel_ms().items()}, "GPU span", s.get_gpu_ms().round(3), "ambiguous wave-steps", s.get_ambiguous_steps(), "iterations run", s.get_iterations_run())

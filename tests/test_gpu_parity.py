@@ -634,6 +634,25 @@ def test_small_registration_persistent_kernel(hip, orc, P, full, mode, es):
         assert o.iterations_run() < I                      # (SVGD-ICP: the displacement threshold may or may not trip in 12 steps; equality is the point)
 
 
+def test_blocking_align_follows_the_stop_flag(hip, orc):
+    """The reference's shipped settings (config/geodeAlpha.yaml): 100 iterations, early stop at 5e-4, 10 particles, max_dist 3.
+    The blocking svnicp_align enqueues the iterations in chunks and stops enqueuing soon after the device has stopped;
+    svnicp_align_async enqueues all 100 (the rest return at once).  Same result, same iteration count, equal to the oracle."""
+    P, B, M, K, I = 10, 1100, 9000, 100, 100
+    src, tgt = hip.scans.random_clouds(B, M, seed=41, extent=20.0)
+    init = hip.scans.make_particles(P, seed=P) * 0.2
+    cfg = dict(iterations=I, lr=1.0, max_dist=3.0, check_early_stop=True, convergence_threshold=5e-3, knn_count=K, svn_full_grad=False)   # (5e-3 on these random clouds: stops at iteration 22)
+    o = orc.Solver(init, **cfg); o.add_cloud(src, tgt, init); o.stein_align()
+    assert 8 < o.iterations_run() < I
+    a = _hip_solver(hip, init, trace=False, **cfg); a.add_cloud(src, tgt, init)
+    assert a.stein_align() == hip.SteinICPState.ALIGN_SUCCESS
+    b = _hip_solver(hip, init, trace=False, **cfg); b.add_cloud(src, tgt, init); b.stein_align_async(); b.synchronize()
+    for s in (a, b):
+        assert s.get_iterations_run() == o.iterations_run() and int(s.get_runtime()[2]) == o.finish_iter()
+        assert np.allclose(s.get_particles(), o.get_particles(), rtol=0, atol=TIGHT)
+    assert np.array_equal(a.get_particles(), b.get_particles()) and np.array_equal(a.get_particle_history(), b.get_particle_history())
+
+
 def test_two_particles_zero_bandwidth_goes_nan_like_the_reference(hip, orc):
     """Two particles: the lower median of the four pair distances {0, 0, d, d} is 0, the RBF bandwidth is 0 and the first
     Stein step is NaN (SVNICP.cpp:262, 218-252).  From then on the reference's masking BY MULTIPLICATION (SVGDICP.cpp:331-333)

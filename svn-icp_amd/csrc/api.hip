@@ -79,6 +79,7 @@ struct svnicp_ctx {
   DevBuf<float4> tablef, tablea;
   DevBuf<unsigned int> small_bar;   // persistent small-registration kernel: arrivals, generation, error word
   bool small_launched = false;      // the last svnicp_align_async ran the persistent kernel (its error word is checked at the next synchronisation)
+  bool defer_fin = false;           // svnicp_align's own loop: iteration i's early-stop decision is taken by iteration i + 1's search kernel
   DevBuf<uint8_t> kbest;
   DevBuf<int32_t> kidx;
   // source-row sharding (svnicp_set_row_shard): this context holds rows of a larger scan; its per-iteration sums are one of
@@ -829,6 +830,12 @@ int svnicp_iter_accumulate(svnicp_ctx* c, int it) {
   a.p_lo = c->p_lo; a.p_hi = c->p_hi; a.max_dist = c->prm.max_dist; a.partial = c->partial.p; a.ctl = c->ctl.p;
   a.corr = c->prm.record_trace ? c->trcorr.p + (size_t)it * c->P * c->B : nullptr;
   a.svgd = c->prm.mode == SVNICP_MODE_SVGD ? 1 : 0;
+  a.fin_iteration = -1;
+  if (c->defer_fin && it >= 1) {   // the previous iteration's early-stop decision rides on this iteration's search launch
+    const UpdateArgs up = update_args(c, it - 1);
+    a.fin_iteration = it - 1; a.fin_P = c->P; a.fin_thr = c->prm.convergence_threshold; a.fin_norms = update_step_norms(up);
+    a.fin_pose = c->pose_out.p; a.fin_history = c->history.p; a.fin_ctl = c->ctl.p;
+  }
   if (c->tune.full_corr) {
     // correspondence = full (the reference's get_correspondence, SVGDICP.cpp:274-298): every particle's transformed source
     // against the WHOLE target, K = 1 — P exact nearest-neighbour searches per iteration through the stage-A machinery
@@ -892,14 +899,14 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
   } else if (small_chain(c)) {
     u.sums = c->partial.p; u.n_ranks = c->plan.grid_x; u.sums_stride = c->plan.Ppad * kNSums; u.sums_out = c->sums.p;
     HIPCHK(c, launch_update_prepare_median(u, c->stream));
-    HIPCHK(c, launch_update_direction(u, c->stream));
+    HIPCHK(c, launch_update_direction(u, c->stream, !(c->defer_fin && it < c->prm.iterations - 1)));
   } else {
     // pair statistics: forked at the start of the iteration; a caller that skipped svnicp_iter_accumulate gets them here
     if (const int rc = fork_median(c, it)) return rc;
     HIPCHK(c, launch_update_prepare(u, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     c->median_pending = false;
-    HIPCHK(c, launch_update_direction(u, c->stream));
+    HIPCHK(c, launch_update_direction(u, c->stream, !(c->defer_fin && it < c->prm.iterations - 1)));
   }
   HIPCHK(c, prof_end(c));
   return SVNICP_OK;
@@ -977,6 +984,9 @@ static int align_enqueue(svnicp_ctx* c, bool follow_stop) {
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_flags), 3 * sizeof(int), hipHostMallocDefault));
     for (auto& e : c->ev_chunk) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  // early stop: iteration i's decision is taken by iteration i + 1's search kernel (the last iteration keeps k_upd_finish)
+  c->defer_fin = c->prm.check_early_stop && !c->prm.record_trace && c->plan.f32 == 3 && !c->tune.full_corr && c->P >= 2 && !update_one_kernel(c);
+  struct Reset { bool& f; ~Reset() { f = false; } } reset_defer{c->defer_fin};
   for (int it = 0; it < c->prm.iterations; ++it) {
     if ((rc = svnicp_iter_accumulate(c, it))) return rc;
     if ((rc = svnicp_iter_update(c, it))) return rc;

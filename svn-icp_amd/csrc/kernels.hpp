@@ -150,6 +150,14 @@ struct AccumArgs {
   const int32_t* full_idx;  // correspondence = full: nearest target index of every (particle, source point), [P][B]; else nullptr
   int pts_per_block, spts_per_block;  // split variant: source points per workgroup (accumulate / search kernel)
   unsigned int* ticket;               // fused one-particle iteration: arrival counter of the accumulate kernel's workgroups
+  // the PREVIOUS iteration's early-stop decision, taken by workgroup (0, 0) of the search kernel instead of a k_upd_finish
+  // launch of its own (svnicp_align's loop; fin_iteration < 0: nothing to decide)
+  int fin_iteration, fin_P;
+  double fin_thr;
+  const double* fin_norms;            // [P] step norms of that iteration (uctl + UCTL_NORM)
+  const double* fin_pose;             // [6][P] pose_out
+  float* fin_history;                 // [I][6][P]
+  int* fin_ctl;                       // [0] stop flag, [1] finish_iter
 };
 struct AccumPlan { int PW, WP, TP, grid_x, grid_y, tiles_per_block, Ppad, RS, f32, K, sgrid_x, pts_per_block, spts_per_block; int64_t n_tiles; size_t smem;
                    int small; /* split variant, few (point, particle) pairs: at most kSmallChainBlocks accumulate workgroups, see api.hip small_chain */ };
@@ -234,7 +242,8 @@ hipError_t launch_update_prepare_median(const UpdateArgs& a, hipStream_t st);   
 bool small_registration_supported(int PW, int WP, int K);
 hipError_t launch_small_registration(const AccumPlan& plan, AccumArgs a, const UpdateArgs& u, int iterations, unsigned int* bar,
                                      int num_cus, hipStream_t st);
-hipError_t launch_update_direction(const UpdateArgs& a, hipStream_t st);
+hipError_t launch_update_direction(const UpdateArgs& a, hipStream_t st, bool finish = true);   // finish: k_upd_finish behind it when the step needs one
+const double* update_step_norms(const UpdateArgs& a);   // [P] norms the early-stop decision averages
 hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles, double* sums, const int* ctl,
                                   hipStream_t st);
 size_t update_uctl_doubles(int P);

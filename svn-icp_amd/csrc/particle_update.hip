@@ -1601,11 +1601,12 @@ hipError_t launch_small_registration(const AccumPlan& plan, AccumArgs a, const U
   return launch_small_t<64, 2, 6, true>(a, u, s, grid, smem, st);
 }
 
-hipError_t launch_update_direction(const UpdateArgs& a, hipStream_t st) {
+hipError_t launch_update_direction(const UpdateArgs& a, hipStream_t st, bool finish) {
   hipLaunchKernelGGL(k_upd_direction, dim3((a.P + 3) / 4), dim3(256), 0, st, a);
-  if (a.check_early_stop || a.trH) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
+  if (finish && (a.check_early_stop || a.trH)) hipLaunchKernelGGL(k_upd_finish, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();
 }
+const double* update_step_norms(const UpdateArgs& a) { return a.uctl + UCTL_NORM; }
 
 hipError_t launch_reduce_partials(const double* partial, int nblk, int Ppad, int p_lo, int n_particles, double* sums, const int* ctl,
                                   hipStream_t st) {

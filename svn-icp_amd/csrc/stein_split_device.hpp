@@ -190,6 +190,32 @@ constexpr float kEpsBf16 = (float)SVNICP_SEARCH_EPS_U * 5.9604644775390625e-08f;
 template <int PW, int WP, int NRB, bool TAIL>
 __device__ __forceinline__ void search_body(const AccumArgs& a, int bx, int by) {
   if (a.ctl[0]) return;
+  if (a.fin_iteration >= 0 && bx == 0 && by == 0) {
+    // The previous iteration's early-stop decision (SVNICP.cpp:95-101 / SVGDICP.cpp:123-131) and, if the run goes on, its
+    // history row (SVNICP.cpp:103-107): k_upd_finish's work, done here by one workgroup instead of a launch of its own.  The
+    // other workgroups of THIS launch may already be searching (a search only writes scratch); every later launch sees the
+    // flag.  Fixed tree: every replica decides alike.
+    __shared__ double sh_fin[NT];
+    __shared__ int sh_fin_stop;
+    const int ftid = threadIdx.x, FP = a.fin_P;
+    double fs = 0.0;
+    for (int p = ftid; p < FP; p += NT) fs += a.fin_norms[p];
+    sh_fin[ftid] = fs;
+    __syncthreads();
+    for (int off = NT / 2; off > 0; off >>= 1) {
+      if (ftid < off) sh_fin[ftid] += sh_fin[ftid + off];
+      __syncthreads();
+    }
+    if (ftid == 0) {
+      const double m = sh_fin[0] / FP;
+      const int stop = (float)m < (float)a.fin_thr;
+      if (stop) { a.fin_ctl[0] = 1; a.fin_ctl[1] = a.fin_iteration + 1; }
+      sh_fin_stop = stop;
+    }
+    __syncthreads();
+    if (sh_fin_stop) return;
+    for (int e = ftid; e < 6 * FP; e += NT) a.fin_history[(size_t)a.fin_iteration * 6 * FP + e] = (float)a.fin_pose[e];
+  }
   constexpr int BW = kWave / PW;   // source points per wave step (1, 2, 4)
   constexpr int CBP = PW / 16;     // 16-particle column blocks per source point (4, 2, 1)
   constexpr int NPT = 4 / CBP;     // distinct source points per wave step

@@ -117,7 +117,9 @@ int svnicp_set_max_dist(svnicp_ctx *ctx, double max_dist);
  * or a negative svnicp_status. */
 int svnicp_align(svnicp_ctx *ctx);
 /* same work, enqueued only (no host sync): for benchmarking / pipelining; results are valid after
- * svnicp_synchronize() */
+ * svnicp_synchronize().  With check_early_stop every iteration is enqueued (those behind the stop return at once on the
+ * device); the blocking svnicp_align instead follows the device's stop flag and stops enqueuing a few iterations after it
+ * (the reference breaks out of its loop, SVNICP.cpp:95-101) — same result, less idle launching when the run stops early. */
 int svnicp_align_async(svnicp_ctx *ctx);
 
 /* results — caller-allocated outputs, copied device -> host */

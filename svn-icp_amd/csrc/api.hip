@@ -433,6 +433,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "single") { if (v == "fused") t.single_fused = 1; else if (v == "split") t.single_fused = 0; else ok = false; }
   else if (k == "chain") { if (v == "auto") { t.small_chain = 1; t.persistent = 0; } else if (v == "persistent") { t.small_chain = 1; t.persistent = 1; }
                            else if (v == "general") { t.small_chain = 0; t.persistent = 0; } else ok = false; }
+  else if (k == "median") { if (v == "auto") t.median_inline = -1; else if (v == "stream") t.median_inline = 0; else if (v == "inline") t.median_inline = 1; else ok = false; }
   else if (k == "correspondence") { if (v == "fast") t.full_corr = 0; else if (v == "full") t.full_corr = 1; else ok = false; }
   else return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: unknown option '" + k + "'");
   if (!ok) return fail(c, SVNICP_ERR_INVALID, "svnicp_set_option: bad value '" + v + "' for option '" + k + "'");
@@ -803,8 +804,18 @@ static bool update_one_kernel(const svnicp_ctx* c) { return c->P < 2 || (c->tune
 // (the prepare lanes add them), and the pair statistics share the prepare kernel's launch on the main stream
 static bool small_chain(const svnicp_ctx* c) { return c->plan.f32 == 3 && c->plan.small && c->plan.grid_x <= kSmallChainBlocks; }
 
+// general chain, up to 128 particles (the one-workgroup pair statistics): they run as the last workgroup of the prepare
+// kernel's launch on the main stream.  The second stream hid their 12 us behind the search kernel, but its fork and join
+// (event record / wait on both sides, one more launch) cost more: C3 7.25 -> 6.99 ms, C2 2.72 -> 2.56 ms per registration,
+// and 0.25 ms less host time to enqueue a registration.  Above 128 particles the three-kernel chain stays on the second stream.
+constexpr int kMedianInlineMaxP = 128;
+static bool median_inline(const svnicp_ctx* c) {
+  if (c->P < 2 || c->P > 128 || c->P > c->tune.fused_update_max_p || update_one_kernel(c)) return false;
+  return c->tune.median_inline == 1 || (c->tune.median_inline == -1 && c->P <= kMedianInlineMaxP);
+}
+
 static int fork_median(svnicp_ctx* c, int it) {
-  if (update_one_kernel(c) || c->median_pending || small_chain(c)) return SVNICP_OK;
+  if (update_one_kernel(c) || c->median_pending || small_chain(c) || median_inline(c)) return SVNICP_OK;
   if (c->tune.debug && !c->dbg_upd) { HIPCHK(c, hipMalloc(&c->dbg_upd, 8 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->dbg_upd, 0, 8 * sizeof(unsigned long long))); }
   const UpdateArgs u = update_args(c, it);
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -898,6 +909,9 @@ int svnicp_iter_update(svnicp_ctx* c, int it) {
     else HIPCHK(c, launch_update(u, c->stream));
   } else if (small_chain(c)) {
     u.sums = c->partial.p; u.n_ranks = c->plan.grid_x; u.sums_stride = c->plan.Ppad * kNSums; u.sums_out = c->sums.p;
+    HIPCHK(c, launch_update_prepare_median(u, c->stream));
+    HIPCHK(c, launch_update_direction(u, c->stream, !(c->defer_fin && it < c->prm.iterations - 1)));
+  } else if (median_inline(c)) {
     HIPCHK(c, launch_update_prepare_median(u, c->stream));
     HIPCHK(c, launch_update_direction(u, c->stream, !(c->defer_fin && it < c->prm.iterations - 1)));
   } else {

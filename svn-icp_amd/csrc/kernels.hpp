@@ -181,6 +181,7 @@ struct Tuning {
   int small_chain = 1;           // small registrations: no k_reduce_partials, Stein-step front in one launch on the main stream (0: the general chain, A/B)
   int persistent = 0;            // 1: svnicp_align runs all iterations of a small-chain registration in ONE cooperative launch (k_small_registration;
                                  // measured SLOWER than the four launches per iteration on this eight-XCD part: off by default, option chain=persistent)
+  int median_inline = -1;        // pair statistics in the prepare kernel's launch on the main stream also in the general chain: -1 automatic (P <= 128), 0 never (second stream), 1 the same as automatic
   int full_corr = 0;             // 1: correspondence = full — per-particle exact NN over the whole target (SVGDICP.cpp:274-298)
 };
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune);

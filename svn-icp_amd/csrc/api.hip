@@ -430,6 +430,7 @@ int svnicp_set_option(svnicp_ctx* c, const char* name, const char* value) {
   else if (k == "scan_split") ok = num(0, 16, &t.scan_split);
   else if (k == "group_stride") ok = num(0, 1 << 30, &t.group_stride);
   else if (k == "accum_min_steps") ok = num(0, 1 << 20, &t.accum_min_steps);
+  else if (k == "brute_qb") { ok = num(0, 6, &t.brute_qb); }   // queries per workgroup of k_knn_brute, 0 = automatic
   else if (k == "single") { if (v == "fused") t.single_fused = 1; else if (v == "split") t.single_fused = 0; else ok = false; }
   else if (k == "chain") { if (v == "auto") { t.small_chain = 1; t.persistent = 0; } else if (v == "persistent") { t.small_chain = 1; t.persistent = 1; }
                            else if (v == "general") { t.small_chain = 0; t.persistent = 0; } else ok = false; }
@@ -662,7 +663,7 @@ static int stage_a(svnicp_ctx* c, const double* qsrc, const Pose0& pose, int K, 
       HIPCHK(c, hipMemsetAsync(c->dbg_phase, 0, 8 * sizeof(unsigned long long), c->stream));
       k.phase_cycles = c->dbg_phase;
     }
-    HIPCHK(c, launch_knn_brute(k, c->stream));
+    HIPCHK(c, launch_knn_brute(k, c->num_cus, c->tune.brute_qb, c->stream));
     if (k.phase_cycles) {
       unsigned long long h[8];
       HIPCHK(c, hipMemcpyAsync(h, c->dbg_phase, sizeof h, hipMemcpyDeviceToHost, c->stream));

@@ -47,7 +47,9 @@ struct KnnBruteArgs {
   unsigned long long* phase_cycles;   // optional [8]: thread-0 cycles per phase, summed over the workgroups (option debug)
 };
 bool knn_brute_applicable(int64_t B, int64_t M, int K);
-hipError_t launch_knn_brute(const KnnBruteArgs& a, hipStream_t st);
+int knn_brute_queries_per_block(int64_t n, int num_cus);
+// queries_per_block: 0 = knn_brute_queries_per_block(n, num_cus); 1..6 = as given (option brute_qb, A/B)
+hipError_t launch_knn_brute(const KnnBruteArgs& a, int num_cus, int queries_per_block, hipStream_t st);
 
 // ---------------- Stage A fast variant (knn_scan.hip) ----------------
 struct KnnScanArgs {
@@ -182,6 +184,7 @@ struct Tuning {
   int persistent = 0;            // 1: svnicp_align runs all iterations of a small-chain registration in ONE cooperative launch (k_small_registration;
                                  // measured SLOWER than the four launches per iteration on this eight-XCD part: off by default, option chain=persistent)
   int median_inline = -1;        // pair statistics in the prepare kernel's launch on the main stream also in the general chain: -1 automatic (P <= 128), 0 never (second stream), 1 the same as automatic
+  int brute_qb = 0;              // brute-force stage A: queries per workgroup, 0 automatic (knn_brute_queries_per_block)
   int full_corr = 0;             // 1: correspondence = full — per-particle exact NN over the whole target (SVGDICP.cpp:274-298)
 };
 AccumPlan plan_accumulate(int n_particles, int64_t B, int K, int num_cus, int f32, const Tuning& tune);

@@ -7,7 +7,7 @@
 // 3e7–6e7 point pairs.  k_knn_brute evaluates every pair in float64 with the reference's arithmetic (SVGDICP.cpp:201-215,
 // knn_cpu.cpp:35-67: q = (s·R0ᵀ) + t0, d² = ((dx·dx)+dy·dy)+dz·dz unfused) and selects by radix on the bit pattern of d²
 // (non-negative doubles order like unsigned integers):
-//   a workgroup = 4 queries x all targets (1024 threads, thread <-> every 1024th target, AoS rows as given: no copy of the cloud);
+//   a workgroup = 1..6 queries (chosen per launch, see QB below) x all targets (1024 threads, thread <-> every 1024th target, AoS rows as given: no copy of the cloud);
 //   pass A   every thread keeps the minimum d² of ITS targets: 1024 values from 1024 distinct targets per query, so their
 //            K-th smallest (bisection on the bit patterns, one wave per query) is a bound that at least K targets meet —
 //            and a tight one: the K nearest targets mostly fall to different threads (the trick of k_knn_seed);
@@ -26,8 +26,13 @@ namespace svnicp {
 
 namespace {
 
-constexpr int kQB = 4;          // queries per workgroup = waves per workgroup (wave q analyses query q's histogram)
-constexpr int kCap = 256;       // pool entries per query (one entry per thread of the query's quarter of the workgroup in the ranking)
+// QB (template parameter): queries per workgroup, 1..6 (wave q analyses query q's histogram).  The targets a thread loads are
+// shared by the workgroup's queries, so more queries per workgroup cost less per query — but the kernel's 97+ registers at
+// 1024 threads mean ONE workgroup per CU, and a launch of a few more workgroups than CUs runs two rounds, the second nearly
+// empty: launch_knn_brute picks the QB with the least rounds x time per round (1 113 queries, the scan-to-map loop's size, on
+// 256 CUs: 279 workgroups of four = two rounds; 223 of five = one).
+constexpr int kQBMax = 6;
+constexpr int kCap = 256;       // pool entries per query (one entry per thread of a quarter of the workgroup in the ranking)
 constexpr int kNTB = 1024;      // threads per workgroup: 16 waves, four per SIMD — the sweeps are f64 dependency chains, occupancy hides them
 constexpr int kBins = 1024;
 constexpr int kWinBase = (1023 - 64) << 3;   // key 0 <-> d² < 2^-64 (incl. 0), key 1023 <-> d² >= 2^64 (incl. +inf)
@@ -50,7 +55,7 @@ __device__ __forceinline__ int win_key(unsigned long long bits) {
   return d > kBins - 1 ? kBins - 1 : d;
 }
 
-template <bool COLLECT>
+template <bool COLLECT, int kQB>
 __device__ __forceinline__ void brute_pass(const KnnBruteArgs& a, const double (&qx)[kQB], const double (&qy)[kQB], const double (&qz)[kQB],
                                            int nq, const QState* st, unsigned int (*hist)[kBins], double (*pd)[kCap], int (*pi)[kCap],
                                            unsigned int* pn, int64_t j0, int64_t stride, int64_t n_steps, bool only_window) {
@@ -115,7 +120,7 @@ __device__ __forceinline__ void brute_pass(const KnnBruteArgs& a, const double (
 // pass A / pass B: four targets per thread and trip, the next four already in flight.
 //   BOUND:   per-thread minimum of d² per query (a NaN never replaces a number)
 //   !BOUND:  collect the targets with bits(d²) <= lim[q] (a limit of 0 with take0[q] false: the query takes no part)
-template <bool BOUND>
+template <bool BOUND, int kQB>
 __device__ __forceinline__ void sweep_pass(const KnnBruteArgs& a, const double (&qx)[kQB], const double (&qy)[kQB], const double (&qz)[kQB],
                                            int nq, double (&mn)[kQB], const unsigned long long (&lim)[kQB], const bool (&part)[kQB],
                                            double (*pd)[kCap], int (*pi)[kCap], unsigned int* pn, int64_t n_steps) {
@@ -167,6 +172,7 @@ __device__ __forceinline__ void sweep_pass(const KnnBruteArgs& a, const double (
   }
 }
 
+template <int kQB>
 __global__ __launch_bounds__(kNTB) void k_knn_brute(KnnBruteArgs a) {
   __shared__ unsigned int s_hist[kQB][kBins];
   __shared__ double s_pd[kQB][kCap];
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(kNTB) void k_knn_brute(KnnBruteArgs a) {
     double mn[kQB];
 #pragma unroll
     for (int q = 0; q < kQB; ++q) { mn[q] = __builtin_huge_val(); lim[q] = 0ull; part[q] = false; }
-    sweep_pass<true>(a, qx, qy, qz, nq, mn, lim, part, s_pd, s_pi, s_pn, steps_all);
+    sweep_pass<true, kQB>(a, qx, qy, qz, nq, mn, lim, part, s_pd, s_pi, s_pn, steps_all);
 #pragma unroll
     for (int q = 0; q < kQB; ++q) s_min[q][tid] = mn[q];
   }
@@ -300,8 +306,10 @@ __global__ __launch_bounds__(kNTB) void k_knn_brute(KnnBruteArgs a) {
   }
   // pass B: collect within the bound
   {
-    double mn[kQB] = {0.0, 0.0, 0.0, 0.0};
-    sweep_pass<false>(a, qx, qy, qz, nq, mn, lim, part, s_pd, s_pi, s_pn, steps_all);
+    double mn[kQB];
+#pragma unroll
+    for (int q = 0; q < kQB; ++q) mn[q] = 0.0;
+    sweep_pass<false, kQB>(a, qx, qy, qz, nq, mn, lim, part, s_pd, s_pi, s_pn, steps_all);
   }
   __syncthreads();
   stamp(2);
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(kNTB) void k_knn_brute(KnnBruteArgs a) {
     }
     __syncthreads();
     for (int round = 0; round < 13; ++round) {   // window histogram, then 7 + 4 rounds at most
-      brute_pass<false>(a, qx, qy, qz, nq, s_st, s_hist, s_pd, s_pi, s_pn, 0, 1, steps_all, false);
+      brute_pass<false, kQB>(a, qx, qy, qz, nq, s_st, s_hist, s_pd, s_pi, s_pn, 0, 1, steps_all, false);
       __syncthreads();
       if (tid == 0) s_open = 0;
       __syncthreads();
@@ -329,39 +337,37 @@ __global__ __launch_bounds__(kNTB) void k_knn_brute(KnnBruteArgs a) {
       if (s_open == 0) break;
       __syncthreads();
     }
-    brute_pass<true>(a, qx, qy, qz, nq, s_st, s_hist, s_pd, s_pi, s_pn, 0, 1, steps_all, false);
+    brute_pass<true, kQB>(a, qx, qy, qz, nq, s_st, s_hist, s_pd, s_pi, s_pn, 0, 1, steps_all, false);
     __syncthreads();
   }
   stamp(3);
 
   // rank by counting under (d², original index), ascending output (pad like torch::full(..., 0), knn_cpu.cpp:25-26)
-  {   // threads [256 q, 256 q + 256) rank query q's pool
-    const int q = tid >> 8, e = tid & 255;
-    if (q < nq) {
-      const int64_t b = qb0 + q;
-      const int n = (int)(s_pn[q] < (unsigned int)kCap ? s_pn[q] : (unsigned int)kCap);
-      if (e < n) {
-        const double de = s_pd[q][e];
-        const int ie = s_pi[q][e];
-        int rank = 0;
-        int f = 0;
-        for (; f + 8 <= n; f += 8) {   // eight broadcast reads in flight per trip (one at a time, the loop waits out the LDS latency)
-          double df[8];
-          int jf[8];
+  for (int q = tid >> 8; q < nq; q += kNTB / 256) {   // threads [256 g, 256 g + 256) rank the pools of queries g, g + 4, ...
+    const int e = tid & 255;
+    const int64_t b = qb0 + q;
+    const int n = (int)(s_pn[q] < (unsigned int)kCap ? s_pn[q] : (unsigned int)kCap);
+    if (e < n) {
+      const double de = s_pd[q][e];
+      const int ie = s_pi[q][e];
+      int rank = 0;
+      int f = 0;
+      for (; f + 8 <= n; f += 8) {   // eight broadcast reads in flight per trip (one at a time, the loop waits out the LDS latency)
+        double df[8];
+        int jf[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { df[u] = s_pd[q][f + u]; jf[u] = s_pi[q][f + u]; }
+        for (int u = 0; u < 8; ++u) { df[u] = s_pd[q][f + u]; jf[u] = s_pi[q][f + u]; }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) rank += (df[u] < de || (df[u] == de && jf[u] < ie)) ? 1 : 0;
-        }
-        for (; f < n; ++f) {
-          const double df = s_pd[q][f];
-          const int jf = s_pi[q][f];
-          rank += (df < de || (df == de && jf < ie)) ? 1 : 0;
-        }
-        if (rank < K) { a.out_idx[b * K + rank] = ie; a.out_d2[b * K + rank] = de; }
+        for (int u = 0; u < 8; ++u) rank += (df[u] < de || (df[u] == de && jf[u] < ie)) ? 1 : 0;
       }
-      for (int k = n + e; k < K; k += 256) { a.out_idx[b * K + k] = 0; a.out_d2[b * K + k] = 0.0; }
+      for (; f < n; ++f) {
+        const double df = s_pd[q][f];
+        const int jf = s_pi[q][f];
+        rank += (df < de || (df == de && jf < ie)) ? 1 : 0;
+      }
+      if (rank < K) { a.out_idx[b * K + rank] = ie; a.out_d2[b * K + rank] = de; }
     }
+    for (int k = n + e; k < K; k += 256) { a.out_idx[b * K + k] = 0; a.out_d2[b * K + k] = 0.0; }
   }
   stamp(4);
 }
@@ -373,11 +379,39 @@ bool knn_brute_applicable(int64_t B, int64_t M, int K) {
   return K >= 1 && K <= 128 && B >= 1 && M >= 1 && M < (1ll << 31) && (double)B * (double)M <= 134217728.0;   // 2^27 pairs
 }
 
-hipError_t launch_knn_brute(const KnnBruteArgs& a, hipStream_t st) {
+template <int QB>
+static hipError_t launch_qb(const KnnBruteArgs& a, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_knn_brute<QB>, dim3((unsigned)((n + QB - 1) / QB)), dim3(kNTB), 0, st, a);
+  return hipGetLastError();
+}
+
+// queries per workgroup for n queries on num_cus CUs (one workgroup per CU at a time): fewest rounds x (time of one round).
+// One round, measured at 50 000 targets, K = 100 (tests/gpu_time_brute.py): 43, 58, 66, 77, 93, 104 us for 1..6 queries
+// (8: 197 us — 12 spilled registers; not instantiated).  1 113 queries: 152 -> 98 us; 700: 79 -> 70; 300: 77 -> 58.
+int knn_brute_queries_per_block(int64_t n, int num_cus) {
+  static const int round_us[kQBMax + 1] = {0, 43, 58, 66, 77, 93, 104};
+  const int64_t cus = num_cus > 0 ? num_cus : 256;
+  int best = 4;
+  int64_t best_cost = -1;
+  for (int qb = 1; qb <= kQBMax; ++qb) {
+    const int64_t blocks = (n + qb - 1) / qb, rounds = (blocks + cus - 1) / cus, cost = rounds * round_us[qb];
+    if (best_cost < 0 || cost < best_cost) { best = qb; best_cost = cost; }
+  }
+  return best;
+}
+
+hipError_t launch_knn_brute(const KnnBruteArgs& a, int num_cus, int queries_per_block, hipStream_t st) {
   const int64_t n = a.b_hi - a.b_lo;
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_knn_brute, dim3((unsigned)((n + kQB - 1) / kQB)), dim3(kNTB), 0, st, a);
-  return hipGetLastError();
+  switch (queries_per_block > 0 ? queries_per_block : knn_brute_queries_per_block(n, num_cus)) {
+    case 1: return launch_qb<1>(a, n, st);
+    case 2: return launch_qb<2>(a, n, st);
+    case 3: return launch_qb<3>(a, n, st);
+    case 4: return launch_qb<4>(a, n, st);
+    case 5: return launch_qb<5>(a, n, st);
+    case 6: return launch_qb<6>(a, n, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace svnicp

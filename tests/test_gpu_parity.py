@@ -373,6 +373,31 @@ def test_stage_a_brute_force_exact_ties(hip, orc, K):
     assert np.array_equal(s.get_candidate_dist2(), od)
 
 
+@pytest.mark.parametrize("qb", [1, 2, 3, 4, 5, 6])
+def test_stage_a_brute_force_queries_per_workgroup(hip, orc, qb):
+    """knn_brute.hip is instantiated for 1..6 queries per workgroup (launch_knn_brute picks the one with the fewest
+    rounds of workgroups over the CUs); every instantiation gives the oracle's rows — ordinary clouds (pass A / pass B),
+    2000-fold duplicates (the histogram path incl. index bits), a query count that is no multiple of qb, M < K."""
+    rng = np.random.default_rng(11 + qb)
+    init = np.zeros((6, 1))
+    K = 100
+    cfg = dict(iterations=1, lr=1.0, max_dist=1.0, knn_count=K, svn_full_grad=False)
+    src, tgt = hip.scans.random_clouds(8 * 37 + 3, 5000, seed=40 + qb, extent=10.0)
+    centers = rng.normal(size=(4, 3)) * 5
+    dup = np.repeat(centers, 2000, axis=0).astype(np.float32).astype(np.float64)
+    dup = dup[rng.permutation(dup.shape[0])]
+    qdup = centers[rng.integers(0, 4, 61)] + rng.normal(size=(61, 3)) * 0.1
+    qdup[:4] = dup[:4]
+    for s_, t_ in ((src, tgt), (qdup, dup), (src[:13], tgt[:40])):
+        s = _hip_solver(hip, init, trace=False, **cfg)
+        s.set_option("brute_qb", qb)
+        s.add_cloud(s_, t_, init); s.stein_align()
+        assert s.get_knn_fallbacks() == 0
+        oi, od = orc.knn_topk(s_, t_, K)
+        assert np.array_equal(s.get_candidates().astype(np.int64), oi)
+        assert np.array_equal(s.get_candidate_dist2(), od)
+
+
 def test_stage_a_survivor_arena_exhaustion_is_survivable(hip, orc):
     """Every query sits next to 2000 duplicated targets: each needs three 512-slot chunks beyond its own pool row, 40 000
     queries ask for 120 000 chunks and the arena holds 32 768.  Queries that get no chunk are marked failed (no hang, no

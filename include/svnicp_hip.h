@@ -132,7 +132,7 @@ int svnicp_get_particle_history(svnicp_ctx *ctx, float *outIx6P);    /* SVGDICP.
 int svnicp_get_runtime(svnicp_ctx *ctx, double out3[3]);             /* SVGDICP.h:94-96 {knn_s, update_s, finish_iter} */
 
 /* test / profiling knobs of a context, by name (the product configuration is the default of every one):
- *   knn = auto|v1|v2|brute|tiles   fallback_sliced_max = <n>      accum = split|valu|f64
+ *   knn = auto|v1|v2|brute|tiles   brute_qb = 0..6   fallback_sliced_max = <n>      accum = split|valu|f64
  *   update = auto|fused     fused_update_max_p = <P>       wgpcu = <search>,<accumulate>     tp = <points>    debug = 0|1
  *   single = fused|split    chain = auto|general|persistent   median = auto|stream|inline          correspondence = fast|full
  * The environment variable SVNICP_OPTIONS ("name=value;name=value") is read once, in svnicp_create. */

@@ -668,9 +668,10 @@ static int stage_a(svnicp_ctx* c, const double* qsrc, const Pose0& pose, int K, 
       unsigned long long h[8];
       HIPCHK(c, hipMemcpyAsync(h, c->dbg_phase, sizeof h, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      const double nwg = (double)((b_hi - b_lo + 3) / 4);
-      fprintf(stderr, "[svnicp] k_knn_brute thread-0 cycles per workgroup: pass A %.0f, bound %.0f, pass B %.0f, general path %.0f, rank + write %.0f\n",
-              h[0] / nwg, h[1] / nwg, h[2] / nwg, h[3] / nwg, h[4] / nwg);
+      const int qb = c->tune.brute_qb > 0 ? c->tune.brute_qb : knn_brute_queries_per_block(b_hi - b_lo, c->num_cus);
+      const double nwg = (double)((b_hi - b_lo + qb - 1) / qb);
+      fprintf(stderr, "[svnicp] k_knn_brute (%d queries per workgroup) thread-0 cycles per workgroup: pass A %.0f, bound %.0f, pass B %.0f, general path %.0f, rank + write %.0f\n",
+              qb, h[0] / nwg, h[1] / nwg, h[2] / nwg, h[3] / nwg, h[4] / nwg);
     }
   } else if (c->knn_variant == 2) {
     const int64_t n = b_hi - b_lo;

@@ -1,6 +1,6 @@
 """Soak run of the brute-force stage A alone (not a pytest file; run on the GPU box): random structures (integer lattices,
 2000-fold duplicates, UTM-sized offsets, millimetre scale, thin planes — the fuzz generator of tests/test_gpu_parity.py),
-sizes from one query / one target up to 2^27 pairs, K, and every queries-per-workgroup instantiation: candidate rows and
+sizes from one query / one target up to 1.3e8 pairs, K, and every queries-per-workgroup instantiation: candidate rows and
 their d² against the oracle, bit for bit.  The float32 pre-filter of knn_brute.hip must never lose a neighbour.
    python tests/gpu_soak_brute.py [n_cases] [first_seed]"""
 import os, sys, time

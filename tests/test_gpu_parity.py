@@ -274,7 +274,7 @@ def test_full_correspondence_mode_refusals(hip):
 def test_stage_a_variants_bit_exact(hip, orc, B, M, K):
     """The four stage-A kernels — streaming (knn_topk.hip, option knn=v1), seeded f32 pre-filter
     (knn_scan.hip, v2), Morton-tile pruning (knn_tiles.hip, K <= 128) and the one-launch brute force for small
-    registrations (knn_brute.hip, the default up to 2^27 point pairs and K <= 128) — must all give indices and dist²
+    registrations (knn_brute.hip, the default up to 2^28 point pairs and K <= 128) — must all give indices and dist²
     bit-identical to the oracle's f64 brute force."""
     src, tgt = hip.scans.random_clouds(B, M, seed=B + K, extent=40.0)
     src = src + np.array([100.0, -50.0, 3.0])      # large coordinates: the filter slack must cover them

@@ -35,7 +35,7 @@ namespace {
 // empty: launch_knn_brute picks the QB with the least rounds x time per round (1 113 queries, the scan-to-map loop's size, on
 // 256 CUs: 279 workgroups of four = two rounds; 223 of five = one).
 constexpr int kQBMax = 6;
-constexpr int kCap = 256;       // pool entries per query (one entry per thread of a quarter of the workgroup in the ranking)
+constexpr int kCap = 256;       // pool entries per query (four threads per entry in the ranking)
 constexpr int kNTB = 1024;      // threads per workgroup: 16 waves, four per SIMD — the sweeps are f64 dependency chains, occupancy hides them
 constexpr int kBins = 1024;
 constexpr int kWinBase = (1023 - 64) << 3;   // key 0 <-> d² < 2^-64 (incl. 0), key 1023 <-> d² >= 2^64 (incl. +inf)
